@@ -1,0 +1,514 @@
+"""TrainingNeural - drop-in API of ``python/Training/TrainingNeural.py`` on MI355X.
+
+Same public names, signatures, return values, prints and checkpoint layout as the
+reference module; the arithmetic of the hot loop (``train_single_epoch`` :341-390,
+``GCNSoftmax.forward`` :79-85, ``evaluate_model`` :537-570) runs in the hand-written HIP
+kernels of ``libgcnmaxcut_hip.so`` through :class:`gcn_max_cut_amd.engine.FusedEngine`.
+There is no CPU fallback: without the HIP library and a GPU the compute entry points
+raise :class:`gcn_max_cut_amd.hip.HipExtensionError`.
+
+Deliberately kept quirks: the features are the padded adjacency (Q1),
+the loss pads to a hard-coded 1000 (Q2), the "best" state aliases the live parameters
+(Q4), one Adam step per graph in dataset order (Q5), early-stop bookkeeping (Q8), save
+names (Q9).  Extension (keyword-only / environment, default off): ``graphs_per_step`` > 1
+switches to batched steps (one Adam step per batch of graphs, summed loss), and when
+``torch.distributed`` is initialised each rank trains on its shard of every batch with one
+RCCL all-reduce of the flat gradient per step.
+"""
+from __future__ import annotations
+
+import os
+import random  # noqa: F401  (reference namespace)
+from dataclasses import dataclass
+from itertools import chain, permutations
+from time import time
+from typing import Callable, Dict, List, Optional, Tuple  # noqa: F401
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
+
+from .. import hip
+from ..commons import open_file, save_object  # noqa: F401
+from ..engine import PARAM_ORDER, FusedEngine, shard_for_rank
+from ..graph import GraphBatch, GraphHandle
+
+TORCH_DEVICE = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+TORCH_DTYPE = torch.float32
+_LOSS_PAD = 1000  # TrainingNeural.py:171
+
+
+@dataclass
+class TrainingConfig:
+    """Configuration class for training parameters (TrainingNeural.py:36-67)."""
+    n_nodes: int = 1000
+    dim_embedding: Optional[int] = None
+    hidden_dim: Optional[int] = None
+    dropout: float = 0.0
+    number_classes: int = 3
+    learning_rate: float = 0.001
+    number_epochs: int = 1000
+    tolerance: float = 1e-4
+    patience: int = 20
+    prob_threshold: float = 0.5
+    A: float = 0.0
+    C: float = 1.0
+    penalty: float = 1000.0
+    save_directory: Optional[str] = None
+    save_frequency: int = 100
+
+    def __post_init__(self):
+        if self.dim_embedding is None:
+            self.dim_embedding = self.n_nodes
+        if self.hidden_dim is None:
+            self.hidden_dim = self.dim_embedding // 2
+
+
+# --------------------------------------------------------------------------- model
+class GraphConv(nn.Module):
+    """Parameter container with DGL ``GraphConv``'s layout and init (weight ``[in,out]``,
+    xavier-uniform; bias zeros).  The arithmetic lives in the HIP library."""
+
+    def __init__(self, in_feats: int, out_feats: int):
+        super().__init__()
+        self._in_feats, self._out_feats = in_feats, out_feats
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats))
+        self.bias = nn.Parameter(torch.empty(out_feats))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight)
+        nn.init.zeros_(self.bias)
+
+    def extra_repr(self):
+        return f"in={self._in_feats}, out={self._out_feats}, normalization=both"
+
+
+class _GCNForward(torch.autograd.Function):
+    """softmax(conv2(relu(conv1(A)))) with a HIP backward, for callers that build their own
+    loss from the probabilities (the reference's override/one-hot/compute_loss chain)."""
+
+    @staticmethod
+    def forward(ctx, net, batch, *params):
+        eng = net.engine()
+        ws = torch.empty(eng.workspace_bytes(batch, True), dtype=torch.uint8, device=eng.device)
+        P, _, _ = eng.forward(batch, ws=ws)
+        ctx.net, ctx.batch, ctx.ws = net, batch, ws
+        ctx.save_for_backward(P)
+        return P
+
+    @staticmethod
+    def backward(ctx, gp):
+        (P,) = ctx.saved_tensors
+        eng = ctx.net.engine()
+        g = eng.backward_from_gp(ctx.batch, P, gp.to(torch.float32), ws=ctx.ws)
+        return (None, None) + tuple(g[k].clone() for k in PARAM_ORDER)
+
+
+class GCNSoftmax(nn.Module):
+    """Graph Convolutional Network with softmax output (TrainingNeural.py:69-85)."""
+
+    def __init__(self, in_feats: int, hidden_size: int, num_classes: int, dropout: float, device):
+        super().__init__()
+        self.dropout_frac = dropout
+        self.conv1 = GraphConv(in_feats, hidden_size).to(device)
+        self.conv2 = GraphConv(hidden_size, num_classes).to(device)
+        self._engine: Optional[FusedEngine] = None
+
+    def engine(self) -> FusedEngine:
+        """The fused engine owning this model's parameters (created on first use)."""
+        if self._engine is None:
+            w1, w2 = self.conv1.weight, self.conv2.weight
+            self._engine = FusedEngine(w1.shape[0], w1.shape[1], w2.shape[1], hip.require_gpu())
+        if not self._engine.owns(self):
+            self._engine.adopt(self)
+        return self._engine
+
+    def forward(self, g, inputs):
+        if self.training and self.dropout_frac > 0.0:
+            raise NotImplementedError("dropout > 0 is not implemented on the fused HIP path "
+                                      "(every reference configuration uses dropout=0.0)")
+        eng = self.engine()
+        batch = graph_batch_of(g, inputs, eng.device)
+        params = [dict(self.named_parameters())[k] for k in PARAM_ORDER]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _GCNForward.apply(self, batch, *params)
+        P, _, _ = eng.forward(batch)
+        return P
+
+
+def graph_batch_of(g: GraphHandle, inputs, device) -> GraphBatch:
+    """Single-graph device batch for ``net(g, inputs)``, cached on the handle."""
+    if not isinstance(g, GraphHandle):
+        raise TypeError(f"expected a GraphHandle (made by process_graphs_from_folder), got {type(g)}")
+    vals = g.edge_values(inputs)
+    key = ("batch", None if vals is None else id(vals), str(device))
+    b = g._cache.get(key)
+    if b is None:
+        b = GraphBatch([g], [vals], device)
+        g._cache[key] = b
+    return b
+
+
+# --------------------------------------------------------------------------- loss helpers (torch ops)
+def override_fixed_nodes(h):
+    """Rows 0,1,2 <- e0,e1,e2 with straight-through gradient (TrainingNeural.py:87-94)."""
+    eye = torch.eye(3, dtype=h.dtype, device=h.device)
+    head = eye + h[:3] - h[:3].detach()
+    return torch.cat([head, h[3:].clone()], dim=0)
+
+
+def max_to_one_hot(tensor):
+    """One-hot of the first maximum, straight-through (TrainingNeural.py:96-102)."""
+    hot = torch.zeros_like(tensor)
+    hot[torch.argmax(tensor)] = 1.0
+    return hot + tensor - tensor.detach()
+
+
+def apply_max_to_one_hot(output):
+    """Row-wise :func:`max_to_one_hot` without the Python loop (TrainingNeural.py:104-106)."""
+    hot = F.one_hot(torch.argmax(output, dim=1), output.shape[1]).to(output.dtype)
+    return hot + output - output.detach()
+
+
+def extend_matrix_torch_training(matrix, N):
+    size = matrix.shape[0]
+    if N <= size:
+        return matrix
+    out = torch.zeros((N, N), dtype=matrix.dtype, device=matrix.device)
+    out[:size, :size] = matrix
+    return out
+
+
+def extend_matrix_torch(matrix, N, torch_dtype=None, torch_device=None):
+    """[n,n] -> [n,N] zero-padded (TrainingNeural.py:137-152)."""
+    size = matrix.shape[0]
+    if N < size:
+        raise ValueError("N should be greater than or equal to the original matrix size.")
+    out = torch.zeros(size, N, dtype=matrix.dtype, device=matrix.device)
+    out[:size, :size] = matrix
+    if torch_dtype is not None:
+        out = out.type(torch_dtype)
+    if torch_device is not None:
+        out = out.to(torch_device)
+    return out
+
+
+def calculate_HC_vectorized(s, adjacency_matrix):
+    """Total weight of cut edges, ``sum(A * (1 - pad(S S^T, 1000))) / 2`` (TrainingNeural.py:154-176)."""
+    same = extend_matrix_torch(s @ s.T, _LOSS_PAD)
+    return torch.sum(adjacency_matrix * (1 - same)) / 2
+
+
+def compute_loss(s, adjacency_matrix, A: float = 0, C: float = 1, penalty: float = 1000):
+    """``C * (-cut)``; ``A`` and ``penalty`` are accepted and unused (TrainingNeural.py:291-309)."""
+    return C * (-1 * calculate_HC_vectorized(s, adjacency_matrix))
+
+
+def terminal_independence_penalty(s, terminal_nodes: List[int]):
+    total = 0
+    for i, a in enumerate(terminal_nodes):
+        for b in terminal_nodes[i + 1:]:
+            total = total + torch.dot(s[a], s[b])
+    return total
+
+
+def find_ac_parameters(graph):
+    top = max(dict(graph.degree()).values())
+    return top + 1, top / 2
+
+
+def generate_terminal_permutations(terminal_dict: Dict):
+    keys = list(terminal_dict.keys())
+    return [dict(zip(keys, perm)) for perm in permutations(terminal_dict.values())]
+
+
+def calculate_all_cut_legacy(q_torch, s):
+    if len(s) == 0:
+        return 0
+    total = 0
+    for k in range(s.shape[1]):
+        col = s[:, k].unsqueeze(0)
+        total = total + (q_torch * (col != col.t()).float()).sum() / 2
+    return total / 2
+
+
+def evaluate_optimal_partitioning(net, dgl_graph, inputs, adjacency_matrix, terminal_dict: Dict):
+    """TrainingNeural.py:253-289 (the permutations are generated but, as in the reference,
+    never handed to the model)."""
+    net.eval()
+    best = float('inf')
+    if dgl_graph.number_of_nodes() < 30:
+        inputs = torch.ones((dgl_graph.number_of_nodes(), 30))
+    with torch.no_grad():
+        for _perm in generate_terminal_permutations(terminal_dict):
+            probs = override_fixed_nodes(net(dgl_graph, inputs))
+            value = calculate_all_cut_legacy(adjacency_matrix, (probs >= 0.5).float())
+            if value < best:
+                best = value
+    return best
+
+
+# --------------------------------------------------------------------------- training
+def setup_model_and_optimizer(config: TrainingConfig):
+    """(model, embedding, optimizer) - TrainingNeural.py:311-339.  The embedding is never
+    used by the forward (Q1) but is part of the optimizer, the checkpoint and the return
+    value, as in the reference."""
+    net = GCNSoftmax(config.dim_embedding, config.hidden_dim, config.number_classes,
+                     config.dropout, TORCH_DEVICE)
+    net = net.type(TORCH_DTYPE).to(TORCH_DEVICE)
+    embed = nn.Embedding(config.n_nodes, config.dim_embedding).type(TORCH_DTYPE).to(TORCH_DEVICE)
+    optimizer = torch.optim.Adam(chain(net.parameters(), embed.parameters()), lr=config.learning_rate)
+    return net, embed, optimizer
+
+
+def _graphs_per_step(explicit: Optional[int]) -> int:
+    if explicit is not None:
+        return max(1, int(explicit))
+    return max(1, int(os.environ.get("GCN_MAXCUT_GRAPHS_PER_STEP", "1")))
+
+
+class FusedTrainer:
+    """Device-resident state of one (model, optimizer) pair: per-step graph batches, loss
+    slots, and the bridge that exposes the fused Adam moments through the torch optimizer
+    (so ``optimizer.state_dict()`` has the reference's layout)."""
+
+    def __init__(self, net: GCNSoftmax, optimizer, config: TrainingConfig, graphs_per_step: int = 1):
+        self.net, self.optimizer, self.config = net, optimizer, config
+        self.eng = net.engine()
+        self.graphs_per_step = graphs_per_step
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self._plan_key = None
+        self._batches: List[GraphBatch] = []
+        self._loss_slots: Optional[torch.Tensor] = None
+        self._out = None
+
+    def prepare(self, dataset: Dict) -> None:
+        key = (id(dataset), len(dataset), self.graphs_per_step, self.world)
+        if key == self._plan_key:
+            return
+        items = list(dataset.values())
+        gps, dev = self.graphs_per_step, self.eng.device
+        self._batches = []
+        for start in range(0, len(items), gps * self.world):
+            group = items[start:start + gps * self.world]
+            mine = [group[i] for i in shard_for_rank(len(group), self.rank, self.world)]
+            handles = [it[0] for it in mine]
+            vals = [h.edge_values(it[1]) for h, it in zip(handles, mine)]
+            self._batches.append(GraphBatch(handles, vals, dev))
+        rmax = max((b.R for b in self._batches), default=0)
+        bmax = max((b.B for b in self._batches), default=0)
+        self._out = (torch.empty((rmax, 3), dtype=torch.float32, device=dev),
+                     torch.empty(rmax, dtype=torch.int32, device=dev))
+        self._loss_slots = torch.zeros((len(self._batches), max(bmax, 1)), dtype=torch.float32, device=dev)
+        self._plan_key = key
+
+    def epoch(self, dataset: Dict) -> float:
+        """One pass over the dataset; returns the cumulative loss (one host sync)."""
+        self.prepare(dataset)
+        eng, cfg = self.eng, self.config
+        self._loss_slots.zero_()
+        for i, batch in enumerate(self._batches):
+            eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+            if self.world > 1:
+                eng.allreduce_grad()
+            eng.adam_step(cfg.learning_rate)
+        per_step = self._loss_slots.sum(dim=1)
+        if self.world > 1:
+            dist.all_reduce(per_step, op=dist.ReduceOp.SUM)
+        # the reference adds one float per optimizer step (loss.item(), :388)
+        return float(sum(per_step.cpu().tolist()))
+
+    def sync_optimizer_state(self) -> None:
+        """Expose step / exp_avg / exp_avg_sq of the fused Adam through ``optimizer.state``."""
+        if self.eng.step_count == 0:
+            return
+        named = dict(self.net.named_parameters())
+        mv, vv = self.eng.views(self.eng.m), self.eng.views(self.eng.v)
+        for k in PARAM_ORDER:
+            self.optimizer.state[named[k]] = {
+                'step': torch.tensor(float(self.eng.step_count)),
+                'exp_avg': mv[k], 'exp_avg_sq': vv[k]}
+
+
+def _trainer_for(net, optimizer, config, graphs_per_step: Optional[int] = None) -> FusedTrainer:
+    gps = _graphs_per_step(graphs_per_step)
+    tr = getattr(net, "_fused_trainer", None)
+    if tr is None or tr.optimizer is not optimizer or tr.graphs_per_step != gps:
+        tr = FusedTrainer(net, optimizer, config, gps)
+        net._fused_trainer = tr
+    tr.config = config
+    return tr
+
+
+def train_single_epoch(dataset: Dict, net, optimizer, embed, config: TrainingConfig,
+                       dataset_files: Optional[List[str]] = None, *,
+                       graphs_per_step: Optional[int] = None) -> float:
+    """One epoch, cumulative loss (TrainingNeural.py:341-390)."""
+    net.train()
+    trainer = _trainer_for(net, optimizer, config, graphs_per_step)
+    if dataset_files is None:
+        dataset_files = ['./nx_test_generated_graph_n200_300_d8_12_t500.pkl']
+    cumulative_loss = 0.0
+    for dataset_file in dataset_files:
+        current = dataset if isinstance(dataset, dict) else open_file(dataset_file)
+        cumulative_loss += trainer.epoch(current)
+    return cumulative_loss
+
+
+def _checkpoint(net, optimizer, embed, epoch, loss_history, config) -> Dict:
+    tr = getattr(net, "_fused_trainer", None)
+    if tr is not None:
+        tr.sync_optimizer_state()
+    return {'epoch': epoch, 'model': net.state_dict(), 'optimizer': optimizer.state_dict(),
+            'loss_history': loss_history, 'inputs': embed.weight, 'config': config}
+
+
+def train_model(dataset: Dict, config: TrainingConfig, dataset_files: Optional[List[str]] = None, *,
+                graphs_per_step: Optional[int] = None) -> Tuple:
+    """Main training function (TrainingNeural.py:392-484):
+    returns ``(model, best_loss, final_epoch, embedding_weights, loss_history)``."""
+    print(f"Starting training with {config.number_epochs} epochs")
+    print(f"Model: {config.n_nodes} nodes, {config.number_classes} classes")
+    print(f"Device: {TORCH_DEVICE}")
+
+    net, embed, optimizer = setup_model_and_optimizer(config)
+    best_loss, best_model_state = float('inf'), None
+    loss_history: List[float] = []
+    patience_counter, prev_loss = 0, float('inf')
+    start_time = time()
+    epoch = -1
+
+    for epoch in range(config.number_epochs):
+        cumulative_loss = train_single_epoch(dataset, net, optimizer, embed, config, dataset_files,
+                                             graphs_per_step=graphs_per_step)
+        loss_history.append(cumulative_loss)
+
+        stalled = cumulative_loss > prev_loss or abs(prev_loss - cumulative_loss) <= config.tolerance
+        if epoch > 0 and stalled:
+            patience_counter += 1
+            if patience_counter >= config.patience:
+                print(f'Early stopping at epoch {epoch}')
+                break
+        else:
+            patience_counter = 0
+
+        if cumulative_loss < best_loss:
+            best_loss = cumulative_loss
+            best_model_state = net.state_dict()  # aliases the live parameters (Q4)
+        prev_loss = cumulative_loss
+
+        if epoch % config.save_frequency == 0:
+            print(f'Epoch: {epoch}, Cumulative Loss: {cumulative_loss:.6f}')
+            if config.save_directory:
+                torch.save(_checkpoint(net, optimizer, embed, epoch, loss_history, config),
+                           f'./epoch_{epoch}_loss_{cumulative_loss:.4f}_{config.save_directory}')
+
+    if best_model_state is not None:
+        net.load_state_dict(best_model_state)
+
+    print(f'Training completed in {time() - start_time:.2f} seconds')
+    print(f'Best loss: {best_loss:.6f}')
+
+    if config.save_directory:
+        final_filename = f'./final_{config.save_directory}'
+        torch.save(_checkpoint(net, optimizer, embed, epoch, loss_history, config), final_filename)
+        print(f'Final model saved to {final_filename}')
+
+    return net, best_loss, epoch, embed.weight, loss_history
+
+
+def train_from_pickle(dataset_filename: str, model_name: str, n_nodes: int = 1000, **kwargs) -> Tuple:
+    """Train from a dataset pickle (TrainingNeural.py:486-513)."""
+    graphs_per_step = kwargs.pop('graphs_per_step', None)
+    config = TrainingConfig(**{'n_nodes': n_nodes, 'save_directory': f'{model_name}.pth', **kwargs})
+    print(f"Loading dataset from {dataset_filename}")
+    dataset = open_file(dataset_filename)
+    return train_model(dataset, config, graphs_per_step=graphs_per_step)
+
+
+def train_multi_class(dataset_filename: str, model_name: str, num_classes: int = 3, **kwargs) -> Tuple:
+    """TrainingNeural.py:515-535."""
+    params = {'number_classes': num_classes, 'save_directory': f'{model_name}.pth', **kwargs}
+    return train_from_pickle(dataset_filename, model_name, **params)
+
+
+def evaluate_model(model, dataset: Dict, config: TrainingConfig) -> Dict:
+    """Average / total loss over a dataset (TrainingNeural.py:537-570): forward, terminal
+    override, argmax decode and cut loss for all graphs in one fused launch sequence."""
+    model.eval()
+    items = list(dataset.values())
+    if not items:
+        return {'average_loss': 0, 'total_loss': 0.0, 'num_samples': 0}
+    eng = model.engine()
+    handles = [it[0] for it in items]
+    vals = [h.edge_values(it[1]) for h, it in zip(handles, items)]
+    batch = GraphBatch(handles, vals, eng.device)
+    _, _, loss = eng.forward(batch, config.C, want_loss=True)
+    total = 0.0
+    for value in loss.cpu().tolist():
+        total += value
+    return {'average_loss': total / len(items), 'total_loss': total, 'num_samples': len(items)}
+
+
+def load_neural_model(model_path: str, config: TrainingConfig):
+    """(model, inputs, loaded_config) from a checkpoint (TrainingNeural.py:572-609)."""
+    import torch.serialization
+    try:
+        torch.serialization.add_safe_globals([TrainingConfig])
+        checkpoint = torch.load(model_path, map_location=TORCH_DEVICE)
+    except Exception:
+        try:
+            checkpoint = torch.load(model_path, map_location=TORCH_DEVICE, weights_only=False)
+        except Exception:
+            with torch.serialization.safe_globals([TrainingConfig]):
+                checkpoint = torch.load(model_path, map_location=TORCH_DEVICE)
+    net, embed, _ = setup_model_and_optimizer(config)
+    net.load_state_dict(checkpoint['model'])
+    return net, checkpoint.get('inputs', embed.weight), checkpoint.get('config', config)
+
+
+def save_neural_model(model, optimizer, embed, epoch: int, loss_history: List,
+                      config: TrainingConfig, model_path: str):
+    """TrainingNeural.py:611-634."""
+    torch.save(_checkpoint(model, optimizer, embed, epoch, loss_history, config), model_path)
+    print(f'Model saved to {model_path}')
+
+
+# --------------------------------------------------------------------------- legacy wrappers (:636-733)
+def get_gnn_legacy(n_nodes: int, gnn_hypers: Dict, opt_params: Dict, torch_device, torch_dtype):
+    return setup_model_and_optimizer(TrainingConfig(
+        n_nodes=n_nodes, dim_embedding=gnn_hypers['dim_embedding'], hidden_dim=gnn_hypers['hidden_dim'],
+        dropout=gnn_hypers['dropout'], number_classes=gnn_hypers['number_classes'],
+        learning_rate=opt_params['lr']))
+
+
+def hyperparameters_legacy(n: int = 80, d: int = 3, p=None, graph_type: str = 'reg',
+                           number_epochs: int = int(1e5), learning_rate: float = 1e-4,
+                           prob_threshold: float = 0.5, tol: float = 1e-4, patience: int = 100):
+    dim_embedding = n
+    return (n, d, p, graph_type, number_epochs, learning_rate, prob_threshold, tol, patience,
+            dim_embedding, int(dim_embedding / 2))
+
+
+def train_legacy_wrapper(model_name: str, filename: str = './testData/nx_generated_graph_n80_d3_t200.pkl',
+                         n: int = 80):
+    return train_from_pickle(filename, model_name, n_nodes=n, learning_rate=0.001, patience=20)
+
+
+def train_2way_neural_legacy(model_name: str, filename: str = './testData/prepareDS.pkl'):
+    return train_multi_class(filename, model_name, num_classes=2, n_nodes=4096,
+                             learning_rate=0.001, patience=20, number_epochs=500)
+
+
+get_gnn = get_gnn_legacy
+hyperParameters = hyperparameters_legacy
+train1 = train_legacy_wrapper
+train_2wayNeural = train_2way_neural_legacy
+FIndAC = find_ac_parameters
+GetOptimalNetValue = evaluate_optimal_partitioning
+calculateAllCut = calculate_all_cut_legacy
+LoadNeuralModel = load_neural_model

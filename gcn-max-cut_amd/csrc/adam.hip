@@ -1,0 +1,65 @@
+// Fused Adam step over one flat fp32 buffer (torch.optim.Adam defaults as constructed at
+// TrainingNeural.py:337 and stepped at :386): exp_avg lerp, exp_avg_sq addcmul, bias
+// corrections, addcdiv - one streaming pass, 28 B/parameter (read p,g,m,v; write p,m,v).
+#include "gmc_common.h"
+#include <math.h>
+
+namespace {
+
+struct AdamArgs {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    long n;
+    float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps;
+};
+
+__device__ __forceinline__ void adam1(float &p, float g, float &m, float &v, const AdamArgs &a) {
+    m = m + (g - m) * a.one_minus_b1;                 // exp_avg.lerp_(grad, 1-beta1)
+    v = fmaf(a.one_minus_b2 * g, g, v * a.b2);        // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);                // param.addcdiv_(m, denom, -step_size)
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+    const long n4 = a.n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<float4 *>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4 *>(a.g)[i];
+        float4 m = reinterpret_cast<float4 *>(a.m)[i];
+        float4 v = reinterpret_cast<float4 *>(a.v)[i];
+        adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
+        adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4 *>(a.p)[i] = p;
+        reinterpret_cast<float4 *>(a.m)[i] = m;
+        reinterpret_cast<float4 *>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0) {  // tail (count % 4)
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < a.n) adam1(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    }
+}
+
+}  // namespace
+
+extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count,
+                            float lr, float beta1, float beta2, float eps, int32_t step,
+                            gmc_stream_t stream) {
+    if (!param || !grad || !m || !v) return GMC_ERR_NULL;
+    if (count < 0 || step < 1) return GMC_ERR_SHAPE;
+    if (!gmc_aligned16(param) || !gmc_aligned16(grad) || !gmc_aligned16(m) || !gmc_aligned16(v))
+        return GMC_ERR_ALIGN;
+    if (count == 0) return GMC_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a{param, grad, m, v, (long)count, 1.0f - beta1, beta2, 1.0f - beta2,
+               (float)((double)lr / bc1), (float)sqrt(bc2), eps};
+    long blocks = ((count >> 2) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}

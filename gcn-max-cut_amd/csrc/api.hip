@@ -1,0 +1,171 @@
+// C-ABI orchestration: the fused forward / training entry points of gcnmaxcut.h.
+// Everything is enqueued on the caller's stream; nothing allocates or synchronises.
+#include "gmc_common.h"
+
+// launchers defined in the kernel files
+int gmc_head_bwd_launch(const gmc_batch *, const float *, const float *, float *, float *, hipStream_t);
+int gmc_hidden_tiles(int R);
+int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
+                          long, float *, int, int, hipStream_t);
+int gmc_colsum_reduce_launch(const float *, int, int, float *, float *, const float *, int, float *,
+                             hipStream_t);
+int gmc_dw1_chunks(int B);
+int gmc_dw1_launch(const gmc_batch *, const float *, long, float *, float *, int, int, hipStream_t);
+
+namespace {
+
+struct Workspace {
+    float *T0;       // [R,F]  (X o dinv)@W1, later Gs = dinv o Gpre
+    float *H;        // [R,F]  relu(conv1), later U = dinv o (A @ Gs)
+    float *Z0;       // [R,3]
+    float *GY2;      // [R,3]
+    float *part;     // [tiles,F,4]
+    float *db2part;  // [B,3]
+    float *dw1part;  // [chunks,N,F]
+    size_t bytes;
+};
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base) {
+    Workspace w{};
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        float *p = base ? reinterpret_cast<float *>(static_cast<char *>(base) + off) : nullptr;
+        off += align_up(floats * sizeof(float));
+        return p;
+    };
+    const size_t R = (size_t)b->R, F = (size_t)m->F;
+    w.T0 = take(R * F);
+    w.H = take(R * F);
+    w.Z0 = take(R * 3);
+    if (training) {
+        w.GY2 = take(R * 3);
+        w.part = take((size_t)gmc_hidden_tiles(b->R) * F * 4);
+        w.db2part = take((size_t)b->B * 3);
+        const int chunks = gmc_dw1_chunks(b->B);
+        w.dw1part = take(chunks > 1 ? (size_t)chunks * m->N * F : 0);
+    }
+    w.bytes = off;
+    return w;
+}
+
+int check(const gmc_batch *b, const gmc_model *m) {
+    if (!b || !m) return GMC_ERR_NULL;
+    if (!b->goff || !b->rowptr || !b->gcol || !b->lcol || !b->dinv) return GMC_ERR_NULL;
+    if (!m->W1 || !m->b1 || !m->W2 || !m->b2) return GMC_ERR_NULL;
+    if (m->K != 3) return GMC_ERR_CLASSES;
+    if (b->B < 0 || b->R < 0 || b->nnz < 0 || m->N <= 0 || m->F <= 0) return GMC_ERR_SHAPE;
+    if (m->F % 4 || m->F > 1024) return GMC_ERR_UNSUPPORTED;  // float4 rows, <= 4 passes per lane
+    if (b->B > 0 && (b->n_max < 3 || b->n_max > GMC_MAX_GRAPH_NODES)) return GMC_ERR_GRAPH_SIZE;
+    if (b->n_max > m->N) return GMC_ERR_SHAPE;  // more nodes than rows of conv1.weight
+    return GMC_OK;
+}
+
+int group_rows(const gmc_batch *b) { return b->uniform_n > 0 ? b->uniform_n : b->n_max; }
+
+int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
+    const long F = m->F;
+    // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
+    int rc = gmc_spmm_f32(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, F,
+                          b->R, m->F, group_rows(b), nullptr, nullptr, st);
+    if (rc) return rc;
+    // layer 1 aggregation + bias + relu, layer 2 feature transform fused in the epilogue
+    return gmc_spmm_f32(b->rowptr, b->gcol, nullptr, b->dinv, w.T0, F, m->b1, 1, w.H, F, b->R,
+                        m->F, group_rows(b), m->W2, w.Z0, st);
+}
+
+int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
+                  hipStream_t st) {
+    const long F = m->F;
+    float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
+    float *Gs = w.T0, *U = w.H;
+    int rc = gmc_hidden_bwd_launch(w.H, F, w.GY2, m->W2, b->dinv, Gs, F, w.part, b->R, m->F, st);
+    if (rc) return rc;
+    rc = gmc_colsum_reduce_launch(w.part, gmc_hidden_tiles(b->R), m->F, dW2, db1, w.db2part, b->B,
+                                  db2, st);
+    if (rc) return rc;
+    // conv1 backward aggregation:  U = dinv o (A @ Gs)
+    rc = gmc_spmm_f32(b->rowptr, b->gcol, nullptr, b->dinv, Gs, F, nullptr, 0, U, F, b->R, m->F,
+                      group_rows(b), nullptr, nullptr, st);
+    if (rc) return rc;
+    return gmc_dw1_launch(b, U, F, dW1, w.dw1part, m->N, m->F, st);
+}
+
+}  // namespace
+
+extern "C" int gmc_version(void) { return GMC_VERSION; }
+
+extern "C" const char *gmc_error_string(int code) {
+    switch (code) {
+        case GMC_OK: return "ok";
+        case GMC_ERR_NULL: return "required pointer is NULL";
+        case GMC_ERR_SHAPE: return "negative or inconsistent sizes";
+        case GMC_ERR_CLASSES: return "number_classes must be 3 (override_fixed_nodes is 3-wide)";
+        case GMC_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
+        case GMC_ERR_WORKSPACE: return "workspace too small";
+        case GMC_ERR_GRAPH_SIZE: return "graph has fewer than 3 or more than GMC_MAX_GRAPH_NODES nodes";
+        case GMC_ERR_UNSUPPORTED: return "unsupported shape (hidden_dim must be a multiple of 4 and <= 1024)";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown gmc error";
+    }
+}
+
+extern "C" size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training) {
+    if (!batch || !model) return 0;
+    return carve(batch, model, training, nullptr).bytes;
+}
+
+extern "C" int gmc_forward(const gmc_batch *batch, const gmc_model *model, float C, void *workspace,
+                           size_t workspace_bytes, float *P, int32_t *S, float *loss,
+                           gmc_stream_t stream) {
+    int rc = check(batch, model);
+    if (rc) return rc;
+    if (!P || !workspace) return GMC_ERR_NULL;
+    Workspace w = carve(batch, model, 0, workspace);
+    if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
+    if (batch->R == 0) return GMC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = forward_body(batch, model, w, st);
+    if (rc) return rc;
+    return gmc_head_f32(batch, w.Z0, model->b2, C, P, S, loss, nullptr, nullptr, stream);
+}
+
+extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C,
+                                 void *workspace, size_t workspace_bytes, float *P, int32_t *S,
+                                 float *loss, float *grad, gmc_stream_t stream) {
+    int rc = check(batch, model);
+    if (rc) return rc;
+    if (!P || !workspace || !grad) return GMC_ERR_NULL;
+    if (!gmc_aligned16(grad)) return GMC_ERR_ALIGN;
+    Workspace w = carve(batch, model, 1, workspace);
+    if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (batch->R == 0) {
+        const size_t n = (size_t)model->N * model->F + model->F + (size_t)model->F * 3 + 3;
+        return (int)hipMemsetAsync(grad, 0, n * sizeof(float), st);
+    }
+    rc = forward_body(batch, model, w, st);
+    if (rc) return rc;
+    rc = gmc_head_f32(batch, w.Z0, model->b2, C, P, S, loss, w.GY2, w.db2part, stream);
+    if (rc) return rc;
+    return backward_body(batch, model, w, grad, st);
+}
+
+extern "C" int gmc_backward_from_gp(const gmc_batch *batch, const gmc_model *model, void *workspace,
+                                    size_t workspace_bytes, const float *P, const float *GP,
+                                    float *grad, gmc_stream_t stream) {
+    int rc = check(batch, model);
+    if (rc) return rc;
+    if (!P || !GP || !workspace || !grad) return GMC_ERR_NULL;
+    if (!gmc_aligned16(grad)) return GMC_ERR_ALIGN;
+    Workspace w = carve(batch, model, 1, workspace);
+    if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (batch->R == 0) {
+        const size_t n = (size_t)model->N * model->F + model->F + (size_t)model->F * 3 + 3;
+        return (int)hipMemsetAsync(grad, 0, n * sizeof(float), st);
+    }
+    rc = gmc_head_bwd_launch(batch, P, GP, w.GY2, w.db2part, st);
+    if (rc) return rc;
+    return backward_body(batch, model, w, grad, st);
+}

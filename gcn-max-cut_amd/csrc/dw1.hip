@@ -1,0 +1,126 @@
+// dW1 = (X o dinv)^T @ GY1, summed over the graphs of the batch (autograd of the layer-1
+// feature transform, TrainingNeural.py:80 via loss.backward() :385).  Because X is the
+// padded adjacency, dW1[v,:] = sum_g sum_{u in nbr_g(v)} X[u,v] * U[g,u,:] with
+// U = dinv o GY1, and rows v >= n_g receive nothing (exactly 0).
+//
+// gather_reduce: one wave per (node id v, graph chunk); CSR-order gather of U rows with
+// 8 rows in flight, graphs ascending; writes either dW1 directly (one chunk) or a
+// per-chunk partial that fold_chunks sums in chunk order.  No atomics: reproducible.
+#include "gmc_common.h"
+
+namespace {
+
+constexpr int kUnroll = 8;
+
+struct Dw1Args {
+    gmc_batch b;
+    const float *U;
+    long ldu;
+    float *out;     // [chunks][N][F] (chunks == 1: dW1 itself)
+    int N;
+    int F;
+    int graphs_per_chunk;
+};
+
+template <int NP>
+__global__ __launch_bounds__(256) void dw1_gather_kernel(Dw1Args a) {
+    const int lane = gmc::lane_id();
+    const int v = gmc::uniform((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (v >= a.N) return;
+    const int chunk = blockIdx.y;
+    const int g0 = chunk * a.graphs_per_chunk;
+    const int g1 = min(a.b.B, g0 + a.graphs_per_chunk);
+    const int F4 = a.F >> 2;
+    bool on[NP];
+    int cc[NP];
+    float4 acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        on[p] = lane + 64 * p < F4;
+        cc[p] = on[p] ? lane + 64 * p : F4 - 1;
+        acc[p] = gmc::f4_zero();
+    }
+#pragma unroll 1
+    for (int g = g0; g < g1; ++g) {
+        // goff[g], goff[g+1] -> is node v part of graph g?
+        const int go = a.b.goff[g + min(lane, 1)];
+        const int r0 = __builtin_amdgcn_readlane(go, 0), r1 = __builtin_amdgcn_readlane(go, 1);
+        if (v >= r1 - r0) continue;
+        const int r = r0 + v;
+        const int rp = a.b.rowptr[r + min(lane, 1)];
+        const int beg = __builtin_amdgcn_readlane(rp, 0), end = __builtin_amdgcn_readlane(rp, 1);
+#pragma unroll 1
+        for (int e0 = beg; e0 < end; e0 += 64) {
+            const int cnt = min(64, end - e0);
+            const int myc = lane < cnt ? a.b.gcol[e0 + lane] : 0;
+            float myv = 1.f;
+            if (a.b.vals) myv = lane < cnt ? a.b.vals[e0 + lane] : 0.f;
+#pragma unroll 1
+            for (int j = 0; j < cnt; j += kUnroll) {
+                float4 x[kUnroll][NP];
+                float w[kUnroll];
+                const float *src[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const long c = __builtin_amdgcn_readlane(myc, j + u);
+                    w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myv), j + u));
+                    src[u] = a.U + c * a.ldu;
+                }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (j + u < cnt) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) x[u][p] = reinterpret_cast<const float4 *>(src[u])[cc[p]];
+                    }
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u)
+                    if (j + u < cnt) {
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) gmc::f4_fma(acc[p], w[u], x[u][p]);
+                    }
+            }
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(a.out + ((long)chunk * a.N + v) * a.F);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+        if (on[p]) dst[lane + 64 * p] = acc[p];
+}
+
+// dW1[i] = sum_chunk part[chunk][i]  (float4 elementwise, chunk ascending)
+__global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, float4 *out, long n4, int chunks) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 s = part[i];
+        for (int c = 1; c < chunks; ++c) gmc::f4_add(s, part[(long)c * n4 + i]);
+        out[i] = s;
+    }
+}
+
+}  // namespace
+
+// chunks the batch is split into for parallelism; scratch = chunks*N*F floats when > 1
+int gmc_dw1_chunks(int B) {
+    if (B <= 4) return 1;
+    const int c = (B + 7) / 8;  // ~8 graphs per wave: 1000 rows x chunks waves
+    return c > 32 ? 32 : c;
+}
+
+int gmc_dw1_launch(const gmc_batch *b, const float *U, long ldu, float *dW1, float *scratch,
+                   int N, int F, hipStream_t st) {
+    if (F % 4 || ldu % 4 || F > 1024) return GMC_ERR_ALIGN;
+    const int chunks = gmc_dw1_chunks(b->B);
+    Dw1Args a{*b, U, ldu, chunks > 1 ? scratch : dW1, N, F, (b->B + chunks - 1) / chunks};
+    dim3 grid((N + 3) / 4, chunks);
+    if (F <= 256) hipLaunchKernelGGL(dw1_gather_kernel<1>, grid, dim3(256), 0, st, a);
+    else if (F <= 512) hipLaunchKernelGGL(dw1_gather_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(dw1_gather_kernel<4>, grid, dim3(256), 0, st, a);
+    GMC_LAUNCH_CHECK();
+    if (chunks > 1) {
+        const long n4 = (long)N * F / 4;
+        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(fold_chunks_kernel, dim3(blocks), dim3(256), 0, st,
+                           reinterpret_cast<const float4 *>(scratch), reinterpret_cast<float4 *>(dW1), n4, chunks);
+        GMC_LAUNCH_CHECK();
+    }
+    return GMC_OK;
+}

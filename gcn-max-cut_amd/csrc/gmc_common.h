@@ -1,0 +1,40 @@
+// Shared device helpers for the gfx950 kernels of libgcnmaxcut_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gcnmaxcut.h"
+
+#define GMC_WAVE 64
+
+#define GMC_LAUNCH_CHECK()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+static inline bool gmc_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+namespace gmc {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (GMC_WAVE - 1)); }
+
+// wave-uniform value -> SGPR so that dependent loads become scalar loads
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Butterfly sum over the 64 lanes; every lane gets the total.  Fixed order => deterministic.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GMC_WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_add(float4 &a, const float4 &b) {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+}
+__device__ __forceinline__ void f4_fma(float4 &a, float s, const float4 &b) {
+    a.x = fmaf(s, b.x, a.x); a.y = fmaf(s, b.y, a.y); a.z = fmaf(s, b.z, a.z); a.w = fmaf(s, b.w, a.w);
+}
+
+}  // namespace gmc

@@ -1,0 +1,223 @@
+// Per-graph "head" of the GCN max-cut step: everything that is [n,3]-shaped.
+//
+// One workgroup owns one graph of the block-diagonal batch and keeps its [n,3] tiles in
+// LDS, so the K=3 aggregations (forward Z = A Z0, backward GY2 = A (dinv*GZ)) never touch
+// HBM between phases.  Reference lines replaced:
+//   TrainingNeural.py:83-84   conv2 aggregate + bias, softmax
+//   TrainingNeural.py:87-94   override_fixed_nodes (rows 0,1,2 <- e0,e1,e2)
+//   TrainingNeural.py:96-106  per-row argmax one-hot (Python loop over n rows there)
+//   TrainingNeural.py:154-176,:291-309  loss = -C * cut(S)   (dense [n,1000] there)
+//   loss.backward() (:385) down to the input of conv2's aggregation:
+//      GP = C * A_val @ onehot(S);  GZ = P o (GP - rowsum(GP o P));  db2 = colsum(GZ);
+//      GY2 = A @ (dinv o GZ)
+// Sums run in CSR / fixed tree order: bitwise reproducible.
+#include "gmc_common.h"
+
+namespace {
+
+constexpr int kHeadThreads = 1024;
+
+struct HeadArgs {
+    gmc_batch b;
+    const float *Z0;
+    const float *b2;
+    float C;
+    float *P;
+    int *S;
+    float *loss;
+    float *GY2;
+    float *db2part;
+};
+
+// Deterministic block sum of up to 4 values per thread; result valid in thread 0.
+__device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16*4] */) {
+    const int lane = gmc::lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = gmc::wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave * 4 + k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float s = 0.f;
+            for (int w = 0; w < nw; ++w) s += red[w * 4 + k];
+            v[k] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.x;
+    const int r0 = a.b.goff[g];
+    const int n = a.b.goff[g + 1] - r0;
+    float *sA = lds;                          // [n*3]  Z0, later dinv*GZ
+    float *sP = lds + 3 * a.b.n_max;          // [n*3]  softmax output
+    int *sS = reinterpret_cast<int *>(lds + 6 * a.b.n_max);  // [n] argmax class
+    float *red = lds + 7 * a.b.n_max;         // [64]
+    const bool train = a.GY2 != nullptr;
+
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) sA[i] = a.Z0[(long)r0 * 3 + i];
+    __syncthreads();
+
+    // phase 1: aggregate, bias, softmax, override, argmax
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        const int r = r0 + l;
+        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int c = a.b.lcol[e];
+            z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2];
+        }
+        const float d = a.b.dinv[r];
+        z0 = fmaf(z0, d, a.b2[0]); z1 = fmaf(z1, d, a.b2[1]); z2 = fmaf(z2, d, a.b2[2]);
+        const float m = fmaxf(z0, fmaxf(z1, z2));
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
+        const float inv = 1.0f / (e0 + e1 + e2);
+        const float p0 = e0 * inv, p1 = e1 * inv, p2 = e2 * inv;
+        a.P[(long)r * 3] = p0; a.P[(long)r * 3 + 1] = p1; a.P[(long)r * 3 + 2] = p2;
+        sP[3 * l] = p0; sP[3 * l + 1] = p1; sP[3 * l + 2] = p2;
+        int s;
+        if (l < 3) {
+            s = l;  // (e_l + p) - p: 1 at l, exactly 0 elsewhere -> argmax is l
+        } else {
+            s = 0;  // torch.argmax: first maximum wins
+            float best = p0;
+            if (p1 > best) { best = p1; s = 1; }
+            if (p2 > best) { s = 2; }
+        }
+        sS[l] = s;
+        if (a.S) a.S[r] = s;
+    }
+    __syncthreads();
+
+    // phase 2: cut value (+ GP, softmax backward, dinv*GZ when training)
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // cut2, db2[0..2]
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        const int r = r0 + l;
+        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
+        const int me = sS[l];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, cut = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int sc = sS[a.b.lcol[e]];
+            const float w = a.b.vals ? a.b.vals[e] : 1.0f;
+            g0 += sc == 0 ? w : 0.f; g1 += sc == 1 ? w : 0.f; g2 += sc == 2 ? w : 0.f;
+            cut += sc != me ? w : 0.f;
+        }
+        acc[0] += cut;
+        if (train) {
+            g0 *= a.C; g1 *= a.C; g2 *= a.C;
+            const float p0 = sP[3 * l], p1 = sP[3 * l + 1], p2 = sP[3 * l + 2];
+            const float dot = g0 * p0 + g1 * p1 + g2 * p2;
+            const float z0 = p0 * (g0 - dot), z1 = p1 * (g1 - dot), z2 = p2 * (g2 - dot);
+            acc[1] += z0; acc[2] += z1; acc[3] += z2;
+            const float d = a.b.dinv[r];
+            sA[3 * l] = z0 * d; sA[3 * l + 1] = z1 * d; sA[3 * l + 2] = z2 * d;
+        }
+    }
+    block_sum4(acc, red);  // contains a __syncthreads(): sA writes are visible after it
+    if (threadIdx.x == 0) {
+        if (a.loss) a.loss[g] = -a.C * (acc[0] * 0.5f);
+        if (train && a.db2part) {
+            a.db2part[g * 3] = acc[1]; a.db2part[g * 3 + 1] = acc[2]; a.db2part[g * 3 + 2] = acc[3];
+        }
+    }
+    if (!train) return;
+
+    // phase 3: GY2 = A @ (dinv o GZ)   (A symmetric: A^T == A)
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        const int r = r0 + l;
+        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int c = a.b.lcol[e];
+            y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2];
+        }
+        a.GY2[(long)r * 3] = y0; a.GY2[(long)r * 3 + 1] = y1; a.GY2[(long)r * 3 + 2] = y2;
+    }
+}
+
+// GY2 for a caller-supplied dLoss/dP (autograd path): same phases 2b/3 as above.
+struct HeadBwdArgs {
+    gmc_batch b;
+    const float *P;
+    const float *GP;
+    float *GY2;
+    float *db2part;
+};
+
+__global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int g = blockIdx.x;
+    const int r0 = a.b.goff[g];
+    const int n = a.b.goff[g + 1] - r0;
+    float *sA = lds;
+    float *red = lds + 3 * a.b.n_max;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        const long r = r0 + l;
+        const float g0 = a.GP[r * 3], g1 = a.GP[r * 3 + 1], g2 = a.GP[r * 3 + 2];
+        const float p0 = a.P[r * 3], p1 = a.P[r * 3 + 1], p2 = a.P[r * 3 + 2];
+        const float dot = g0 * p0 + g1 * p1 + g2 * p2;
+        const float z0 = p0 * (g0 - dot), z1 = p1 * (g1 - dot), z2 = p2 * (g2 - dot);
+        acc[1] += z0; acc[2] += z1; acc[3] += z2;
+        const float d = a.b.dinv[r];
+        sA[3 * l] = z0 * d; sA[3 * l + 1] = z1 * d; sA[3 * l + 2] = z2 * d;
+    }
+    block_sum4(acc, red);
+    if (threadIdx.x == 0) {
+        a.db2part[g * 3] = acc[1]; a.db2part[g * 3 + 1] = acc[2]; a.db2part[g * 3 + 2] = acc[3];
+    }
+    for (int l = threadIdx.x; l < n; l += blockDim.x) {
+        const int r = r0 + l;
+        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        for (int e = beg; e < end; ++e) {
+            const int c = a.b.lcol[e];
+            y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2];
+        }
+        a.GY2[(long)r * 3] = y0; a.GY2[(long)r * 3 + 1] = y1; a.GY2[(long)r * 3 + 2] = y2;
+    }
+}
+
+int check_batch(const gmc_batch *b) {
+    if (!b || !b->goff || !b->rowptr || !b->gcol || !b->lcol || !b->dinv) return GMC_ERR_NULL;
+    if (b->B < 0 || b->R < 0 || b->nnz < 0) return GMC_ERR_SHAPE;
+    if (b->B > 0 && (b->n_max < 3 || b->n_max > GMC_MAX_GRAPH_NODES)) return GMC_ERR_GRAPH_SIZE;
+    return GMC_OK;
+}
+
+}  // namespace
+
+extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, const float *b2, float C,
+                            float *P, int32_t *S, float *loss, float *GY2, float *db2part,
+                            gmc_stream_t stream) {
+    int rc = check_batch(batch);
+    if (rc) return rc;
+    if (!Z0 || !b2 || !P) return GMC_ERR_NULL;
+    if (GY2 && !db2part) return GMC_ERR_NULL;
+    if (batch->B == 0) return GMC_OK;
+    HeadArgs a{*batch, Z0, b2, C, P, S, loss, GY2, db2part};
+    const size_t lds = sizeof(float) * (7 * (size_t)batch->n_max + 64);
+    hipLaunchKernelGGL(head_kernel, dim3(batch->B), dim3(kHeadThreads), lds,
+                       static_cast<hipStream_t>(stream), a);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
+// internal (api.hip)
+int gmc_head_bwd_launch(const gmc_batch *batch, const float *P, const float *GP, float *GY2,
+                        float *db2part, hipStream_t st) {
+    int rc = check_batch(batch);
+    if (rc) return rc;
+    if (batch->B == 0) return GMC_OK;
+    HeadBwdArgs a{*batch, P, GP, GY2, db2part};
+    const size_t lds = sizeof(float) * (3 * (size_t)batch->n_max + 64);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(batch->B), dim3(kHeadThreads), lds, st, a);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}

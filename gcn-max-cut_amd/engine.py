@@ -1,0 +1,153 @@
+"""Fused HIP engine: forward / training step / Adam over the C-ABI library.
+
+Holds the model's four GraphConv tensors as views of ONE flat fp32 buffer
+``[W1 | b1 | W2 | b2]`` (so a single fused Adam sweep and a single RCCL all-reduce cover
+them), the gradient / Adam-moment buffers of the same shape, and the scratch workspace.
+All kernels are enqueued on torch's current HIP stream through ``gcnmaxcut.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .graph import GraphBatch
+
+PARAM_ORDER = ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")
+
+
+def flat_layout(N: int, F: int, K: int) -> Tuple[List[int], int]:
+    sizes = [N * F, F, F * K, K]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    return offs, offs[-1]
+
+
+class FusedEngine:
+    """One per model.  ``adopt`` re-homes a module's parameters into the flat buffer."""
+
+    def __init__(self, N: int, F: int, K: int, device: Optional[torch.device] = None):
+        self.device = device or hip.require_gpu()
+        self.lib = hip.load()
+        if K != 3:
+            raise ValueError("number_classes must be 3: the terminal override is 3-wide "
+                             "(TrainingNeural.py:91-93)")
+        if F % 4 or F > 1024:
+            raise ValueError("hidden_dim must be a multiple of 4 and <= 1024 on this path")
+        self.N, self.F, self.K = N, F, K
+        self.offs, self.count = flat_layout(N, F, K)
+        # + 4 floats of tail: slot `count` carries the summed loss through the all-reduce
+        self.flat = torch.zeros(self.count + 4, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.step_count = 0
+        self._ws: Optional[torch.Tensor] = None
+        self._model = hip.GmcModel()
+        self._refresh_model()
+
+    # ---- parameters
+    def views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        buf = self.flat if buf is None else buf
+        o, N, F, K = self.offs, self.N, self.F, self.K
+        return {"conv1.weight": buf[o[0]:o[1]].view(N, F), "conv1.bias": buf[o[1]:o[2]],
+                "conv2.weight": buf[o[2]:o[3]].view(F, K), "conv2.bias": buf[o[3]:o[4]]}
+
+    def _refresh_model(self) -> None:
+        v = self.views()
+        self._model = hip.GmcModel(N=self.N, F=self.F, K=self.K, reserved=0,
+                                   W1=hip.ptr(v["conv1.weight"]), b1=hip.ptr(v["conv1.bias"]),
+                                   W2=hip.ptr(v["conv2.weight"]), b2=hip.ptr(v["conv2.bias"]))
+
+    def adopt(self, module: torch.nn.Module) -> None:
+        """Make ``module.conv{1,2}.{weight,bias}`` views of the flat buffer (values kept)."""
+        named = dict(module.named_parameters())
+        views = self.views()
+        for k in PARAM_ORDER:
+            p = named[k]
+            if p.data_ptr() != views[k].data_ptr() or p.device != self.device:
+                views[k].copy_(p.detach().to(self.device, torch.float32))
+                p.data = views[k]
+
+    def owns(self, module: torch.nn.Module) -> bool:
+        named = dict(module.named_parameters())
+        views = self.views()
+        return all(named[k].data_ptr() == views[k].data_ptr() for k in PARAM_ORDER)
+
+    # ---- scratch
+    def _workspace(self, batch: GraphBatch, training: bool) -> Tuple[torch.Tensor, int]:
+        need = int(self.lib.gmc_workspace_bytes(batch.ref(), C.byref(self._model), int(training)))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        return self._ws, self._ws.numel()
+
+    # ---- compute
+    def workspace_bytes(self, batch: GraphBatch, training: bool) -> int:
+        return max(256, int(self.lib.gmc_workspace_bytes(batch.ref(), C.byref(self._model), int(training))))
+
+    def forward(self, batch: GraphBatch, C_: float = 1.0, want_loss: bool = False,
+                ws: Optional[torch.Tensor] = None):
+        """P [R,3] (and S [R], loss [B] when ``want_loss``) - TrainingNeural.py:79-85.
+        ``ws``: caller-owned scratch (kept alive for a later :meth:`backward_from_gp`)."""
+        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, False)
+        P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
+        S = torch.empty(batch.R, dtype=torch.int32, device=self.device) if want_loss else None
+        loss = torch.empty(batch.B, dtype=torch.float32, device=self.device) if want_loss else None
+        rc = self.lib.gmc_forward(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
+                                  hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.stream())
+        hip.check(rc, "gmc_forward")
+        return P, S, loss
+
+    def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None):
+        """forward + loss + backward for the batch's summed loss; gradient lands in
+        ``self.grad[:count]`` - TrainingNeural.py:373-385."""
+        ws, nbytes = self._workspace(batch, True)
+        if out is None:
+            P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
+            S = torch.empty(batch.R, dtype=torch.int32, device=self.device)
+            loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
+        else:
+            P, S, loss = out
+        rc = self.lib.gmc_train_fwd_bwd(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
+                                        hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad),
+                                        hip.stream())
+        hip.check(rc, "gmc_train_fwd_bwd")
+        return P, S, loss
+
+    def backward_from_gp(self, batch: GraphBatch, P: torch.Tensor, GP: torch.Tensor,
+                         ws: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Gradients for a caller-supplied dLoss/dP (autograd path); ``ws`` must be the
+        (training-sized) workspace of the forward that produced ``P``."""
+        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, True)
+        rc = self.lib.gmc_backward_from_gp(batch.ref(), C.byref(self._model), hip.ptr(ws), nbytes,
+                                           hip.ptr(P), hip.ptr(GP.contiguous()), hip.ptr(self.grad),
+                                           hip.stream())
+        hip.check(rc, "gmc_backward_from_gp")
+        return self.views(self.grad)
+
+    def adam_step(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """torch.optim.Adam.step over the flat buffer (TrainingNeural.py:386)."""
+        self.step_count += 1
+        rc = self.lib.gmc_adam_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
+                                   hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
+                                   self.step_count, hip.stream())
+        hip.check(rc, "gmc_adam_f32")
+
+    def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""
+        if local_loss_sum is not None:
+            self.grad[self.count] = local_loss_sum
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+        return self.grad[self.count] if local_loss_sum is not None else None
+
+
+def shard_for_rank(n_items: int, rank: int, world: int) -> range:
+    """Contiguous, balanced slice of the dataset for one rank."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))

@@ -1,0 +1,116 @@
+"""ctypes binding of ``libgcnmaxcut_hip.so`` (declared in ``include/gcnmaxcut.h``).
+
+This is the only door from the Python host code to the compute path.  There is no
+CPU fallback: if the shared library is missing, or no HIP device is visible, every
+compute entry point raises (see :func:`require_gpu`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libgcnmaxcut_hip.so")
+
+# every symbol include/gcnmaxcut.h declares (tests check the .so exports all of them)
+SYMBOLS = (
+    "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
+    "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
+    "gmc_backward_from_gp",
+)
+
+MAX_GRAPH_NODES = 4096
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension (or a GPU to run it on) is not available."""
+
+
+class GmcBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("R", C.c_int32), ("nnz", C.c_int32), ("n_max", C.c_int32),
+        ("uniform_n", C.c_int32), ("reserved", C.c_int32),
+        ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
+        ("vals", C.c_void_p), ("dinv", C.c_void_p),
+    ]
+
+
+class GmcModel(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32),
+        ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, f32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+    lib.gmc_version.restype = C.c_int
+    lib.gmc_error_string.restype = C.c_char_p
+    lib.gmc_error_string.argtypes = [C.c_int]
+    lib.gmc_spmm_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, i64, i32, i32, i32, vp, vp, vp]
+    lib.gmc_dense_hw2_f32.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp]
+    lib.gmc_head_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, f32, vp, vp, vp, vp, vp, vp]
+    lib.gmc_adam_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    lib.gmc_workspace_bytes.restype = sz
+    lib.gmc_workspace_bytes.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), C.c_int]
+    lib.gmc_forward.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), f32, vp, sz, vp, vp, vp, vp]
+    lib.gmc_train_fwd_bwd.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), f32, vp, sz, vp, vp, vp, vp, vp]
+    lib.gmc_backward_from_gp.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), vp, sz, vp, vp, vp, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes"):
+            fn.restype = C.c_int
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (no compute; works without a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionError(
+                f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def require_gpu() -> torch.device:
+    """The compute path needs the HIP library *and* a visible GPU; fail loudly otherwise."""
+    load()
+    if not torch.cuda.is_available():
+        raise HipExtensionError(
+            "no HIP device visible: the GCN max-cut compute path runs only on a GPU "
+            "(MI355X/gfx950); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def check(rc: int, what: str) -> None:
+    if rc == 0:
+        return
+    msg = load().gmc_error_string(rc).decode()
+    if rc < 0:
+        raise ValueError(f"{what}: {msg} (gmc error {rc})")
+    raise RuntimeError(f"{what}: HIP error {rc}: {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipExtensionError("tensor is not on a HIP device")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,139 @@
+/* gcnmaxcut.h - C ABI of libgcnmaxcut_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of MJavaadAkhtar/GCN-max-cut: the 2-layer
+ * GraphConv forward/backward, the 3-class cut loss and the Adam update behind
+ * python/Training/TrainingNeural.py.  The reference is pure Python on top of
+ * dgl.nn.pytorch.GraphConv + torch; it has no FFI of its own, so these are the entry
+ * points a ctypes binding inside TrainingNeural.py would call (INTEGRATION.md shows
+ * the stub).  Every comment below names the reference lines an entry point replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE (HBM) pointers
+ *    unless a comment says host; the library borrows them for the duration of the call.
+ *  - every function returns int: 0 ok, <0 argument/shape error (gmc_error_string),
+ *    >0 a hipError_t.  Nothing throws, nothing calls exit.
+ *  - all work is enqueued on the caller's stream (`gmc_stream_t` == hipStream_t);
+ *    no hidden synchronisation, no internal threads, no allocation, so every call can
+ *    be captured into a hipGraph.
+ *  - fp32 row-major, int32 indices.  Results are bitwise reproducible run to run
+ *    (fixed summation orders, no float atomics).
+ */
+#ifndef GCNMAXCUT_H
+#define GCNMAXCUT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMC_VERSION 100 /* 0.1.0 */
+
+typedef void *gmc_stream_t; /* hipStream_t */
+
+enum {
+    GMC_OK = 0,
+    GMC_ERR_NULL = -1,        /* required pointer is NULL */
+    GMC_ERR_SHAPE = -2,       /* negative / inconsistent sizes */
+    GMC_ERR_CLASSES = -3,     /* number_classes != 3: override_fixed_nodes is 3-wide (TrainingNeural.py:91-93) */
+    GMC_ERR_ALIGN = -4,       /* pointer / leading dimension not 16-byte aligned */
+    GMC_ERR_WORKSPACE = -5,   /* workspace too small */
+    GMC_ERR_GRAPH_SIZE = -6,  /* a graph has < 3 or > GMC_MAX_GRAPH_NODES nodes */
+    GMC_ERR_UNSUPPORTED = -7
+};
+
+#define GMC_MAX_GRAPH_NODES 4096 /* per-graph head kernel keeps [n,3] tiles in LDS */
+
+/* A block-diagonal batch of B graphs resident in HBM.  This is the CSR form of what
+ * graphExtender.process_graphs_from_folder emits per graph (graphExtender.py:102-114:
+ * the DGL graph == CSR structure, the padded adjacency == `vals` on that structure).
+ * Built once per dataset by the host (gcn-max-cut_amd/graph.py). */
+typedef struct gmc_batch {
+    int32_t B;             /* graphs in the batch */
+    int32_t R;             /* total nodes = sum n_g */
+    int32_t nnz;           /* total directed edges = sum 2|E_g| */
+    int32_t n_max;         /* max n_g */
+    int32_t uniform_n;     /* n if every graph has n nodes, else 0 (XCD grouping hint) */
+    int32_t reserved;
+    const int32_t *goff;   /* [B+1] first row of each graph */
+    const int32_t *rowptr; /* [R+1] */
+    const int32_t *gcol;   /* [nnz] neighbour as batch row id  (aggregation operand) */
+    const int32_t *lcol;   /* [nnz] neighbour as local node id (row of W1 / column of X) */
+    const float *vals;     /* [nnz] edge weight = X[u,v], or NULL when all ones */
+    const float *dinv;     /* [R] clamp(degree,1)^-1/2  (in == out degree: undirected) */
+} gmc_batch;
+
+/* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):
+ * conv1.weight [N,F], conv1.bias [F], conv2.weight [F,K], conv2.bias [K]. */
+typedef struct gmc_model {
+    int32_t N, F, K, reserved;
+    const float *W1, *b1, *W2, *b2;
+} gmc_model;
+
+int gmc_version(void);
+const char *gmc_error_string(int code);
+
+/* ---- building blocks (each is also used by the fused entry points below) ---------- */
+
+/* Y[r,:] = act( scale[r] * sum_{e in row r} vals[e] * X[col[e],:] + bias ),  r < n_rows.
+ * One CSR SpMM serves: the X@W1 row-gather (col=lcol, X=W1), DGL's update_all(copy_u,sum)
+ * of GraphConv layer 1 (col=gcol, + bias + relu; TrainingNeural.py:80-81) and both
+ * F-wide aggregations of its autograd backward (:385).  vals/scale/bias may be NULL.
+ * group_rows > 0 asks for XCD-grouped scheduling: consecutive runs of that many rows
+ * (one graph) are processed by workgroups of one XCD so neighbour rows are L2 hits.
+ * If W2/Z0 are non-NULL (K must be 3) the layer-2 feature transform is fused into the
+ * epilogue: Z0[r,:] = scale[r] * (Y[r,:] @ W2)   ((H*outdeg^-1/2)@W2, :83). */
+int gmc_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *vals,
+                 const float *scale, const float *X, int64_t ldx, const float *bias, int relu,
+                 float *Y, int64_t ldy, int32_t n_rows, int32_t F, int32_t group_rows,
+                 const float *W2, float *Z0, gmc_stream_t stream);
+
+/* Z0[r,:] = dinv[r] * (H[r,:] @ W2), K == 3, on the matrix cores (v_mfma_f32_16x16x4_f32).
+ * Stand-alone form of the only dense contraction on the path (TrainingNeural.py:83). */
+int gmc_dense_hw2_f32(const float *H, int64_t ldh, const float *dinv, const float *W2,
+                      float *Z0, int32_t n_rows, int32_t F, gmc_stream_t stream);
+
+/* Per-graph head: Z = dinv * (A @ Z0) + b2, P = softmax(Z) (TrainingNeural.py:83-84);
+ * rows 0,1,2 forced to e0,e1,e2 and S = row-argmax, first max wins (:87-106);
+ * loss[g] = -C * cut(S) (:154-176,:291-309).  When GY2 != NULL also the start of
+ * loss.backward(): GP = C*A_val@onehot(S), softmax backward, db2part[g,:] = colsum(GZ),
+ * GY2 = A @ (dinv*GZ).  P [R,3], S [R], loss [B], db2part [B,3], GY2 [R,3]. */
+int gmc_head_f32(const gmc_batch *batch, const float *Z0, const float *b2, float C, float *P,
+                 int32_t *S, float *loss, float *GY2, float *db2part, gmc_stream_t stream);
+
+/* torch.optim.Adam.step (TrainingNeural.py:337,:386) over one flat buffer, fused:
+ * m,v update + bias correction + parameter update in a single sweep. step >= 1. */
+int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count, float lr,
+                 float beta1, float beta2, float eps, int32_t step, gmc_stream_t stream);
+
+/* ---- fused entry points ------------------------------------------------------------ */
+
+/* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
+size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training);
+
+/* GCNSoftmax.forward for every graph of the batch (TrainingNeural.py:79-85):
+ * P[R,3] = softmax(conv2(relu(conv1(A_pad)))).  If S/loss are non-NULL also the decode
+ * and loss of evaluate_model (:555-561). */
+int gmc_forward(const gmc_batch *batch, const gmc_model *model, float C, void *workspace,
+                size_t workspace_bytes, float *P, int32_t *S, float *loss, gmc_stream_t stream);
+
+/* forward + loss + loss.backward() of train_single_epoch's loop body (:373-385) for the
+ * SUM of the batch's per-graph losses.  grad is the flat [W1 | b1 | W2 | b2] buffer
+ * (N*F + F + F*3 + 3 floats) and is overwritten (rows of dW1 no graph reaches are 0). */
+int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C, void *workspace,
+                      size_t workspace_bytes, float *P, int32_t *S, float *loss, float *grad,
+                      gmc_stream_t stream);
+
+/* Backward for a caller-supplied dLoss/dP (autograd.Function path: callers that build
+ * their own loss from GCNSoftmax.forward's output, e.g. the reference's
+ * override_fixed_nodes/apply_max_to_one_hot/compute_loss chain).  Requires the
+ * workspace of the gmc_forward/gmc_train_fwd_bwd call that produced P. */
+int gmc_backward_from_gp(const gmc_batch *batch, const gmc_model *model, void *workspace,
+                         size_t workspace_bytes, const float *P, const float *GP, float *grad,
+                         gmc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCNMAXCUT_H */

@@ -1,0 +1,336 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances: node probabilities 1e-4 (north star), argmax partitions exact,
+loss == -cut exactly, gradients 1e-4 relative to the largest entry."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import ref_dense as R
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pkg(built):
+    built.hip.require_gpu()
+    return built
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_spmm(pkg, rp, cl, vl, scale, X, bias, relu, group_rows=0, W2=None):
+    lib = pkg.hip.load()
+    n, F = rp.size - 1, X.shape[1]
+    d = {k: (None if v is None else dev(v)) for k, v in
+         dict(rp=rp, cl=cl, vl=vl, scale=scale, X=X, bias=bias, W2=W2).items()}
+    Y = torch.full((n, F), float("nan"), device="cuda")
+    Z0 = torch.full((n, 3), float("nan"), device="cuda") if W2 is not None else None
+    p = pkg.hip.ptr
+    rc = lib.gmc_spmm_f32(p(d["rp"]), p(d["cl"]), p(d["vl"]), p(d["scale"]), p(d["X"]), F, p(d["bias"]),
+                          int(relu), p(Y), F, n, F, group_rows, p(d["W2"]), p(Z0), pkg.hip.stream())
+    pkg.hip.check(rc, "gmc_spmm_f32")
+    torch.cuda.synchronize()
+    return Y.cpu().numpy(), None if Z0 is None else Z0.cpu().numpy()
+
+
+def block_diag_csr(specs):
+    """Block-diagonal CSR (global columns) of seeded regular graphs."""
+    rps, cls, off, eoff = [np.zeros(1, np.int32)], [], 0, 0
+    for n, d, s in specs:
+        rp, cl, _ = CO.csr_of(R.regular_graph(n, d, s))
+        rps.append(rp[1:] + eoff)
+        cls.append(cl + off)
+        off += n
+        eoff += cl.size
+    return np.concatenate(rps).astype(np.int32), np.concatenate(cls).astype(np.int32)
+
+
+@pytest.mark.parametrize("F", [500, 256, 64, 16, 1000, 6])
+def test_spmm_pure_sum_is_bit_exact(pkg, F):
+    rp, cl = block_diag_csr([(100, 7, 1), (60, 6, 2), (80, 8, 3)])
+    rng = np.random.RandomState(F)
+    X = rng.standard_normal((rp.size - 1, F)).astype(np.float32)
+    ref = CO.spmm(rp, cl, None, None, X, None, False)
+    got, _ = run_spmm(pkg, rp, cl, None, None, X, None, False)
+    assert np.array_equal(got, ref)  # same CSR summation order, no scaling
+
+
+@pytest.mark.parametrize("F,group", [(500, 0), (500, 100), (128, 60), (12, 0)])
+def test_spmm_epilogues(pkg, F, group):
+    rp, cl = block_diag_csr([(100, 7, 4)] * 9 + [(60, 6, 5)])
+    n = rp.size - 1
+    rng = np.random.RandomState(7)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    vl = rng.randint(1, 4, cl.size).astype(np.float32)
+    scale = rng.rand(n).astype(np.float32) + 0.5
+    bias = rng.standard_normal(F).astype(np.float32)
+    ref = CO.spmm(rp, cl, vl, scale, X, bias, True)
+    got, _ = run_spmm(pkg, rp, cl, vl, scale, X, bias, True, group)
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)
+
+
+def test_spmm_fused_w2_epilogue_and_mfma_kernel(pkg):
+    rp, cl = block_diag_csr([(200, 7, 8), (120, 6, 9)])
+    n, F = rp.size - 1, 500
+    rng = np.random.RandomState(3)
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    scale = (1.0 / np.sqrt(np.diff(rp))).astype(np.float32)
+    bias = rng.standard_normal(F).astype(np.float32) * 0.1
+    W2 = (rng.rand(F, 3).astype(np.float32) - 0.5) * 0.2
+    H, Z0 = run_spmm(pkg, rp, cl, None, scale, X, bias, True, 0, W2)
+    ref = (H.astype(np.float64) * scale[:, None]) @ W2.astype(np.float64)
+    np.testing.assert_allclose(Z0, ref, rtol=1e-5, atol=1e-5)
+    # the matrix-core form of the same contraction
+    lib = pkg.hip.load()
+    Hd, Zm = dev(H), torch.empty((n, 3), device="cuda")
+    p = pkg.hip.ptr
+    rc = lib.gmc_dense_hw2_f32(p(Hd), F, p(dev(scale)), p(dev(W2)), p(Zm), n, F, pkg.hip.stream())
+    pkg.hip.check(rc, "gmc_dense_hw2_f32")
+    np.testing.assert_allclose(Zm.cpu().numpy(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_mfma_dense_integer_exact(pkg):
+    """A=I-style check with asymmetric integer data: exact in fp32, catches layout swaps."""
+    n, F = 37, 48
+    H = (np.arange(n * F).reshape(n, F) % 7 - 3).astype(np.float32)
+    W2 = (np.arange(F * 3).reshape(F, 3) % 5 - 2).astype(np.float32)
+    d = np.ones(n, np.float32) * 2
+    lib = pkg.hip.load()
+    Z = torch.empty((n, 3), device="cuda")
+    p = pkg.hip.ptr
+    pkg.hip.check(lib.gmc_dense_hw2_f32(p(dev(H)), F, p(dev(d)), p(dev(W2)), p(Z), n, F, pkg.hip.stream()), "mfma")
+    assert np.array_equal(Z.cpu().numpy(), 2 * (H @ W2))
+
+
+def model_and_params(pkg, hidden, seed=0):
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=hidden)
+    torch.manual_seed(seed)
+    net, embed, opt = T.setup_model_and_optimizer(cfg)
+    return T, cfg, net, embed, opt, util.np_params(net.state_dict())
+
+
+SPECS_SMALL = [(100, 7, 1000), (50, 6, 1001), (64, 8, 1002), (30, 5, 1003)]
+
+
+@pytest.mark.parametrize("hidden,specs", [(16, SPECS_SMALL), (500, [(500, 7, 1000)]), (500, [(1000, 7, 2000)]),
+                                          (128, [(200, 6, 7), (300, 8, 8)])])
+def test_forward_probabilities_and_partitions(pkg, hidden, specs):
+    T, cfg, net, *_rest, params = model_and_params(pkg, hidden)
+    ds = util.product_dataset(specs)
+    net.eval()
+    for (g, a_pad, nx_g, _t) in ds.values():
+        with torch.no_grad():
+            P = net(g, a_pad).cpu().numpy()
+        rp, cl, vl = CO.csr_of(nx_g)
+        ref = CO.forward(rp, cl, vl, params["conv1.weight"], params["conv1.bias"], params["conv2.weight"],
+                         params["conv2.bias"])["P"]
+        assert np.abs(P - ref).max() < PROB_TOL
+        # reference-structured dense oracle (dense [n,1000] GEMM, DGL order)
+        tp = {k: torch.from_numpy(v) for k, v in params.items()}
+        og = R.graph_from_networkx(nx_g)
+        Pd = R.forward(tp, og, a_pad.cpu()).numpy()
+        assert np.abs(P - Pd).max() < PROB_TOL
+        # argmax partitions: exact wherever the float64 margin is not inside fp32 noise
+        P64 = R.forward_dense_f64(tp, nx_g)
+        srt = np.sort(P64, axis=1)
+        decided = (srt[:, 2] - srt[:, 1]) > 1e-6
+        assert decided.mean() > 0.99
+        assert np.array_equal(P.argmax(1)[decided], P64.argmax(1)[decided])
+        assert np.array_equal(P.argmax(1), ref.argmax(1)) or not decided.all()
+
+
+def test_batched_forward_is_bitwise_the_per_graph_forward(pkg):
+    T, cfg, net, *_ = model_and_params(pkg, 500)
+    ds = util.product_dataset([(1000, 7, 3000 + i) for i in range(6)] + [(500, 6, 1), (300, 8, 2)])
+    eng = net.engine()
+    items = list(ds.values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = eng.forward(batch, 1.0, want_loss=True)
+    for g, it in enumerate(items):
+        single = pkg.GraphBatch([it[0]], None, eng.device)
+        Pg, Sg, lg = eng.forward(single, 1.0, want_loss=True)
+        assert torch.equal(batch.split(P)[g], Pg)
+        assert torch.equal(batch.split(S)[g], Sg)
+        assert float(loss[g]) == float(lg[0])
+
+
+def test_loss_equals_minus_cut_of_argmax_partition(pkg):
+    T, cfg, net, *_ = model_and_params(pkg, 64)
+    ds = util.product_dataset(SPECS_SMALL + [(500, 7, 5)])
+    eng = net.engine()
+    items = list(ds.values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = eng.forward(batch, 1.0, want_loss=True)
+    for g, it in enumerate(items):
+        part = batch.split(S)[g].cpu().numpy()
+        assert list(part[:3]) == [0, 1, 2]
+        assert np.array_equal(part, R.partition_of(batch.split(P)[g].cpu()))
+        assert float(loss[g]) == -float(R.cut_value(part.tolist(), it[2]))
+    res = T.evaluate_model(net, ds, cfg)
+    assert res["num_samples"] == len(items)
+    assert res["total_loss"] == float(loss.sum())
+
+
+def flat_ref_grads(ct):
+    o = np.cumsum([0, ct.N * ct.F, ct.F, ct.F * ct.K, ct.K])
+    return {k: ct.grad[o[i]:o[i + 1]] for i, k in enumerate(("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"))}
+
+
+@pytest.mark.parametrize("hidden,specs", [(16, SPECS_SMALL), (500, [(500, 7, 1000), (500, 6, 1001)]),
+                                          (500, [(1000, 7, 2000 + i) for i in range(9)])])
+def test_step_gradients_match_oracle(pkg, hidden, specs):
+    T, cfg, net, embed, opt, params = model_and_params(pkg, hidden)
+    ds = util.product_dataset(specs)
+    eng = net.engine()
+    items = list(ds.values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = eng.train_fwd_bwd(batch, 1.0)
+    ct = CO.CTrainer(params)
+    ref_loss = ct.step(util.csrs_of(ds))
+    assert np.array_equal(loss.cpu().numpy(), ref_loss)
+    ref = flat_ref_grads(ct)
+    for k, g in eng.views(eng.grad).items():
+        g, r = g.cpu().numpy().ravel(), ref[k]
+        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
+    # rows of dW1 that no graph reaches are exactly zero
+    nmax = max(s[0] for s in specs)
+    assert float(eng.views(eng.grad)["conv1.weight"][nmax:].abs().max() if nmax < 1000 else 0.0) == 0.0
+
+
+def test_step_gradients_match_torch_autograd_oracle(pkg):
+    T, cfg, net, embed, opt, params = model_and_params(pkg, 16)
+    ds = util.product_dataset(SPECS_SMALL)
+    eng = net.engine()
+    items = list(ds.values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    eng.train_fwd_bwd(batch, 1.0)
+    ods = util.oracle_dataset(SPECS_SMALL)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    _, grads, _ = R.loss_and_grads(tp, list(ods.values()))
+    for k, g in eng.views(eng.grad).items():
+        r = grads[k].numpy()
+        assert np.abs(g.cpu().numpy() - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
+
+
+def test_weighted_edges_and_loss_scale(pkg):
+    T, cfg, net, embed, opt, params = model_and_params(pkg, 32)
+    from gcn_max_cut_amd.DataGenerator import graphExtender as GE
+    specs = [(80, 7, 21), (40, 6, 22)]
+    graphs, terms = util.weighted_copy(specs)
+    ds = GE.process_graphs_from_folder(graphs, terms, 1000)
+    eng = net.engine()
+    items = list(ds.values())
+    vals = [it[0].edge_values(it[1]) for it in items]
+    assert all(v is not None for v in vals)
+    batch = pkg.GraphBatch([it[0] for it in items], vals, eng.device)
+    P, S, loss = eng.train_fwd_bwd(batch, 2.5)
+    ct = CO.CTrainer(params, Cc=2.5)
+    ref_loss = ct.step(util.csrs_of(ds))
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-6)
+    ref = flat_ref_grads(ct)
+    for k, g in eng.views(eng.grad).items():
+        r = ref[k]
+        assert np.abs(g.cpu().numpy().ravel() - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
+
+
+def test_fused_adam_matches_torch_adam(pkg):
+    lib = pkg.hip.load()
+    n = 502003
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p, m, v = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 ** float(step - 2))
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        hp = pkg.hip.ptr
+        pkg.hip.check(lib.gmc_adam_f32(hp(p), hp(gd), hp(m), hp(v), n, 1e-3, 0.9, 0.999, 1e-8, step,
+                                       pkg.hip.stream()), "adam")
+        np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-7)
+    st = opt.state[ref]
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_sequential_training_follows_oracle(pkg):
+    """Three epochs of the reference schedule (one Adam step per graph)."""
+    T, cfg, net, embed, opt, params = model_and_params(pkg, 16)
+    ds = util.product_dataset(SPECS_SMALL)
+    ct = CO.CTrainer(params, lr=cfg.learning_rate)
+    csrs = util.csrs_of(ds)
+    for epoch in range(3):
+        got = T.train_single_epoch(ds, net, opt, embed, cfg)
+        ref = float(sum(float(ct.step([c])[0]) for c in csrs))
+        assert abs(got - ref) <= 0.02 * abs(ref) + 1e-6, (epoch, got, ref)
+    after = ct.unpack()
+    for k, v in net.state_dict().items():
+        assert np.abs(v.cpu().numpy() - after[k]).max() < 5e-3, k  # a few +-lr Adam steps
+
+
+def test_autograd_path_matches_fused_step(pkg):
+    """net(g, A) -> reference-style helper chain -> .backward() uses the HIP backward."""
+    T, cfg, net, embed, opt, params = model_and_params(pkg, 32)
+    ds = util.product_dataset([(100, 7, 31)])
+    (g, a_pad, nx_g, _t), = ds.values()
+    net.train()
+    P = net(g, a_pad)
+    assert P.requires_grad
+    s = T.apply_max_to_one_hot(T.override_fixed_nodes(P))
+    loss = T.compute_loss(s, a_pad, cfg.A, cfg.C, cfg.penalty)
+    opt.zero_grad()
+    loss.backward()
+    auto = {k: dict(net.named_parameters())[k].grad.clone() for k in pkg.engine.PARAM_ORDER}
+    eng = net.engine()
+    batch = pkg.GraphBatch([g], None, eng.device)
+    _, _, fl = eng.train_fwd_bwd(batch, cfg.C)
+    assert abs(float(loss) - float(fl[0])) < 1e-3
+    for k, v in eng.views(eng.grad).items():
+        assert np.abs((v - auto[k]).cpu().numpy()).max() <= 1e-5 * max(1.0, float(auto[k].abs().max())), k
+
+
+def test_error_behaviour(pkg):
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    import networkx as nx
+    with pytest.raises(ValueError):
+        pkg.FusedEngine(1000, 500, 2)  # 2-way model: the override is 3-wide
+    g = nx.path_graph(5)
+    g.add_node(5)  # isolated node
+    with pytest.raises(pkg.DGLError):
+        pkg.GraphBatch([pkg.from_networkx(g)], None)
+    lib = pkg.hip.load()
+    assert lib.gmc_spmm_f32(None, None, None, None, None, 4, None, 0, None, 4, 1, 4, 0, None, None, None) == -1
+    assert lib.gmc_adam_f32(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 1, None) == -1
+    cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=16)
+    net, _, _ = T.setup_model_and_optimizer(cfg)
+    big = pkg.from_networkx(nx.random_regular_graph(4, 1200, seed=1))
+    with pytest.raises(ValueError):
+        net.engine().forward(pkg.GraphBatch([big], None))  # more nodes than rows of conv1.weight
+
+
+def test_checkpoint_round_trip(pkg, tmp_path, monkeypatch):
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    monkeypatch.chdir(tmp_path)
+    ds = util.product_dataset(SPECS_SMALL)
+    net, best, epoch, emb, hist = T.train_model(ds, T.TrainingConfig(
+        n_nodes=1000, hidden_dim=16, number_epochs=3, save_directory="m.pth", save_frequency=1))
+    assert len(hist) == 3 and best == min(hist)
+    ck = torch.load(tmp_path / "final_m.pth", weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "loss_history", "inputs", "config"}
+    assert sorted(ck["optimizer"]["state"].keys()) == [0, 1, 2, 3]
+    assert set(ck["optimizer"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    net2, inputs, cfg2 = T.load_neural_model(str(tmp_path / "final_m.pth"), T.TrainingConfig(n_nodes=1000, hidden_dim=16))
+    assert tuple(inputs.shape) == (1000, 1000) and cfg2.hidden_dim == 16
+    a, b = T.evaluate_model(net, ds, cfg2), T.evaluate_model(net2, ds, cfg2)
+    assert a == b
