@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GCN max-cut training epochs/sec + SpMM achieved HBM GB/s on
+n=1000 d=7 regular graphs (BASELINE.json), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A *step* is one pass of the hot path (forward, cut loss, backward, RCCL gradient all-reduce
+when N > 1, fused Adam) over this rank's batch of graphs; inputs are resident in HBM before
+the timed region.  Workload at N=1: config[3] of BASELINE.json on one GPU - 160 synthetic
+n=1000 d=7 graphs (R = 160,000 rows, 646 MB algorithmic bytes per F=500 SpMM, beyond the
+256 MiB Infinity Cache).  Scaling is weak: every rank holds its own 160 graphs, so the job
+processes N*160 graphs per step; `value` counts epochs of 160 graphs per second.
+
+The JSON line also carries
+  roofline     - the dominant kernel (row-per-wave CSR SpMM of the layer-1 aggregation,
+                 forward + backward launches): algorithmic bytes / mean launch duration,
+                 durations from HIP events recorded by the library on the launch stream
+                 during the timed steps;
+  cpu_baseline - the CPU oracle (oracle/ref_dense.py, reference-structured torch-CPU port:
+                 dense [n,1000] GEMM, per-row Python one-hot, dense loss, one Adam step per
+                 graph) timed on this box's host cores on a bounded sample, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+EPOCH_GRAPHS = 160  # BASELINE.json configs[3]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs-per-gpu", type=int, default=EPOCH_GRAPHS)
+    ap.add_argument("--nodes", type=int, default=1000, help="nodes per graph")
+    ap.add_argument("--degree", type=int, default=7)
+    ap.add_argument("--hidden", type=int, default=500)
+    ap.add_argument("--mode", choices=["batched", "sequential"], default="batched",
+                    help="batched: one Adam step per rank-batch (DP schedule); sequential: the "
+                         "reference's one Adam step per graph (N=1 only)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true", help="do not record per-kernel HIP events")
+    return ap.parse_args()
+
+
+def regular_graph(n, d, seed):
+    """Synthetic input of SURVEY section 8d: nx.random_regular_graph + unit weights, the
+    reference's generator (DataGenerator/GraphCreator.py:70-90) restated."""
+    import networkx as nx
+    tmp = nx.convert_node_labels_to_integers(nx.random_regular_graph(d=d, n=n, seed=seed))
+    g = nx.Graph()
+    g.add_nodes_from(sorted(tmp.nodes()))
+    g.add_edges_from(tmp.edges)
+    nx.set_edge_attributes(g, 1, "weight")
+    nx.set_edge_attributes(g, 1, "capacity")
+    return g
+
+
+def terminals_of(n, seed):
+    import random
+    return random.Random(seed).sample(range(n), 3)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if args.mode == "sequential" and world > 1:
+        raise SystemExit("sequential mode is the single-GPU reference schedule")
+
+    import gcn_max_cut_amd as pkg
+    from gcn_max_cut_amd.DataGenerator import graphExtender as GE
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+
+    gpg, n, d = args.graphs_per_gpu, args.nodes, args.degree
+    seeds = [3000 + rank * gpg + i for i in range(gpg)]
+    graphs = {i: regular_graph(n, d, s) for i, s in enumerate(seeds)}
+    terms = {i: terminals_of(n, s) for i, s in enumerate(seeds)}
+    with contextlib.redirect_stdout(io.StringIO()):
+        dataset = GE.process_graphs_from_folder(graphs, terms, 1000)
+    assert len(dataset) == gpg, "a synthetic graph was skipped by the terminal normalisation"
+
+    cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=args.hidden, number_epochs=10 ** 9, patience=10 ** 9)
+    torch.manual_seed(0)  # CPU RNG: identical Xavier init on every rank
+    net, embed, opt = T.setup_model_and_optimizer(cfg)
+    gps = gpg if args.mode == "batched" else 1
+    trainer = T.FusedTrainer(net, opt, cfg, graphs_per_step=gps, local_shard=True)
+    net.train()
+    trainer.prepare(dataset)
+    eng = trainer.eng
+    spmm_bytes = trainer._batches[0].spmm_bytes(args.hidden)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.epoch(dataset)
+    launches_per_step = 16 * len(trainer._batches)
+    probe = None if args.no_probe else pkg.hip.Probe(launches_per_step * args.steps)
+    sync()
+    t0 = time.perf_counter()
+    with (probe or contextlib.nullcontext()):
+        for _ in range(args.steps):
+            last_loss = trainer.epoch(dataset)
+        sync()
+        t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    # per-kernel means from the HIP events of the timed steps
+    kernels = {}
+    if probe is not None:
+        for tag, ms in probe.records:
+            kernels.setdefault(tag, []).append(ms)
+    kmean = {k: float(np.mean(v)) for k, v in kernels.items()}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    epochs = args.steps * world * gpg / EPOCH_GRAPHS
+    out = {
+        "metric": "training epochs/sec (n=1000 d=7 graphs)",
+        "value": epochs / elapsed,
+        "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": f"{gpg} x n={n} d={d} regular graphs per GPU (BASELINE configs[3]; "
+                        f"{world * gpg} graphs per step), GCN 1000->{args.hidden}->3, "
+                        f"{args.mode} steps, Adam lr 1e-3",
+            "graphs_per_gpu": gpg, "rows_per_gpu": gpg * n, "nnz_per_gpu": gpg * n * d,
+            "hidden_dim": args.hidden, "mode": args.mode, "epoch_graphs": EPOCH_GRAPHS,
+            "optimizer_steps_per_step": len(trainer._batches),
+            "parallelism": f"dp{world}" if world > 1 else "single",
+        },
+        "last_loss": last_loss,
+        "kernels_ms": {k: round(v, 5) for k, v in sorted(kmean.items())},
+    }
+
+    spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in kernels.get(tag, [])]
+    if spmm and args.mode == "batched":
+        dur = float(np.mean(spmm)) * 1e-3
+        achieved = spmm_bytes / dur / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_spmm.json")
+        if os.path.exists(tfile):
+            rec = json.load(open(tfile))
+            if rec.get("rows") == gpg * n and rec.get("F") == args.hidden:
+                traffic = rec.get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "kernel": "spmm_rows_v4 (layer-1 aggregation, fwd + bwd launches)",
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": spmm_bytes, "mean_launch_us": dur * 1e6,
+            "launches": len(spmm),
+        }
+    else:
+        out["roofline"] = None
+
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, graphs, terms, net)
+        out["parity"] = parity_gate(pkg, T, net, dataset)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, graphs, terms, net):
+    """The oracle as the CPU path: reference-structured torch-CPU training steps (one Adam
+    step per graph, TrainingNeural.py:371-386) on the first graphs of the same workload."""
+    from oracle import ref_dense as R
+    import copy
+    torch.manual_seed(0)
+    threads = torch.get_num_threads()
+    sample = []
+    params = R.init_params(1000, args.hidden, 3, seed=0)
+    tr = R.Trainer(params, lr=1e-3)
+    t_total, k = 0.0, 0
+    for i in sorted(graphs):
+        if t_total > args.cpu_seconds or k >= 64:
+            break
+        g = copy.deepcopy(graphs[i])  # bench graphs were already relabelled in place
+        item = [R.graph_from_networkx(g), R.dense_adjacency(g, 1000), g, [0, 1, 2]]
+        t0 = time.perf_counter()
+        tr.step([item])
+        t_total += time.perf_counter() - t0
+        k += 1
+    per_graph = t_total / max(k, 1)
+    return {
+        "value": 1.0 / (per_graph * EPOCH_GRAPHS), "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)",
+        "cores": threads, "kind": "port",
+        "sample": f"{k} sequential graph-steps (n={args.nodes} d={args.degree}, hidden {args.hidden}) of the "
+                  f"reference-structured torch-CPU oracle, {t_total:.1f} s; {per_graph * 1e3:.1f} ms per graph-step",
+        "host_cpus": os.cpu_count(), "torch": torch.__version__,
+    }
+
+
+def parity_gate(pkg, T, net, dataset):
+    """Parity numbers reported with every perf number: probabilities
+    vs the C oracle on two graphs of the workload with the current weights."""
+    from oracle import c_oracle as CO
+    params = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
+    worst, arg_ok, loss_ok = 0.0, True, True
+    net.eval()
+    for key in list(dataset)[:2]:
+        g, a_pad, nx_g, _t = dataset[key]
+        with torch.no_grad():
+            P = net(g, a_pad).cpu().numpy()
+        rp, cl, vl = CO.csr_of(nx_g)
+        ref = CO.forward(rp, cl, vl, params["conv1.weight"], params["conv1.bias"], params["conv2.weight"],
+                         params["conv2.bias"])["P"]
+        S, loss, _ = CO.loss_grad(rp, cl, vl, ref)
+        worst = max(worst, float(np.abs(P - ref).max()))
+        arg_ok &= bool(np.array_equal(P.argmax(1)[3:], ref.argmax(1)[3:]))
+        res = T.evaluate_model(net, {0: dataset[key]}, T.TrainingConfig())
+        loss_ok &= res["total_loss"] == loss
+    net.train()
+    return {"max_abs_prob_diff": worst, "argmax_equal": arg_ok, "loss_equals_minus_cut": loss_ok,
+            "tolerance": 1e-4}
+
+
+if __name__ == "__main__":
+    main()

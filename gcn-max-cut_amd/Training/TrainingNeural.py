@@ -275,10 +275,14 @@ class FusedTrainer:
     slots, and the bridge that exposes the fused Adam moments through the torch optimizer
     (so ``optimizer.state_dict()`` has the reference's layout)."""
 
-    def __init__(self, net: GCNSoftmax, optimizer, config: TrainingConfig, graphs_per_step: int = 1):
+    def __init__(self, net: GCNSoftmax, optimizer, config: TrainingConfig, graphs_per_step: int = 1,
+                 local_shard: bool = False):
         self.net, self.optimizer, self.config = net, optimizer, config
         self.eng = net.engine()
         self.graphs_per_step = graphs_per_step
+        # local_shard: `dataset` already is this rank's shard (graphs_per_step of ITS graphs per
+        # step); otherwise every rank holds the whole dataset and takes its slice of each group
+        self.local_shard = local_shard
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._plan_key = None
@@ -293,9 +297,10 @@ class FusedTrainer:
         items = list(dataset.values())
         gps, dev = self.graphs_per_step, self.eng.device
         self._batches = []
-        for start in range(0, len(items), gps * self.world):
-            group = items[start:start + gps * self.world]
-            mine = [group[i] for i in shard_for_rank(len(group), self.rank, self.world)]
+        stride = gps if self.local_shard else gps * self.world
+        for start in range(0, len(items), stride):
+            group = items[start:start + stride]
+            mine = group if self.local_shard else [group[i] for i in shard_for_rank(len(group), self.rank, self.world)]
             handles = [it[0] for it in mine]
             vals = [h.edge_values(it[1]) for h, it in zip(handles, mine)]
             self._batches.append(GraphBatch(handles, vals, dev))

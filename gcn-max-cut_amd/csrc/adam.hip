@@ -59,6 +59,7 @@ extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v,
     long blocks = ((count >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
+    GmcProbeScope probe(GMC_K_ADAM, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(adam_kernel, dim3((int)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;

@@ -67,12 +67,12 @@ int group_rows(const gmc_batch *b) { return b->uniform_n > 0 ? b->uniform_n : b-
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
     const long F = m->F;
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
-    int rc = gmc_spmm_f32(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, F,
-                          b->R, m->F, group_rows(b), nullptr, nullptr, st);
+    int rc = gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, F,
+                             b->R, m->F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
     if (rc) return rc;
     // layer 1 aggregation + bias + relu, layer 2 feature transform fused in the epilogue
-    return gmc_spmm_f32(b->rowptr, b->gcol, nullptr, b->dinv, w.T0, F, m->b1, 1, w.H, F, b->R,
-                        m->F, group_rows(b), m->W2, w.Z0, st);
+    return gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, w.T0, F, m->b1, 1, w.H, F, b->R,
+                           m->F, group_rows(b), m->W2, w.Z0, GMC_K_AGG_FWD, st);
 }
 
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
@@ -86,13 +86,70 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
                                   db2, st);
     if (rc) return rc;
     // conv1 backward aggregation:  U = dinv o (A @ Gs)
-    rc = gmc_spmm_f32(b->rowptr, b->gcol, nullptr, b->dinv, Gs, F, nullptr, 0, U, F, b->R, m->F,
-                      group_rows(b), nullptr, nullptr, st);
+    rc = gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, Gs, F, nullptr, 0, U, F, b->R, m->F,
+                         group_rows(b), nullptr, nullptr, GMC_K_AGG_BWD, st);
     if (rc) return rc;
     return gmc_dw1_launch(b, U, F, dW1, w.dw1part, m->N, m->F, st);
 }
 
 }  // namespace
+
+// ---- timing probe -------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProbeRec { int tag; hipEvent_t a, b; };
+struct ProbeState {
+    bool on = false;
+    std::vector<ProbeRec> pool;
+    size_t used = 0;
+} g_probe;
+}  // namespace
+
+void gmc_probe_mark(int tag, bool begin, hipStream_t st) {
+    if (!g_probe.on) return;
+    if (begin) {
+        if (g_probe.used >= g_probe.pool.size()) return;  // capacity exhausted: stop recording
+        ProbeRec &r = g_probe.pool[g_probe.used];
+        r.tag = tag;
+        (void)hipEventRecord(r.a, st);
+    } else {
+        if (g_probe.used >= g_probe.pool.size()) return;
+        ProbeRec &r = g_probe.pool[g_probe.used];
+        if (r.tag != tag) return;
+        (void)hipEventRecord(r.b, st);
+        ++g_probe.used;
+    }
+}
+
+extern "C" int gmc_probe_begin(int32_t capacity) {
+    if (capacity < 0) return GMC_ERR_SHAPE;
+    while ((int)g_probe.pool.size() < capacity) {
+        ProbeRec r{-1, nullptr, nullptr};
+        hipError_t e = hipEventCreate(&r.a);
+        if (e == hipSuccess) e = hipEventCreate(&r.b);
+        if (e != hipSuccess) return (int)e;
+        g_probe.pool.push_back(r);
+    }
+    g_probe.used = 0;
+    g_probe.on = capacity > 0;
+    return GMC_OK;
+}
+
+extern "C" int gmc_probe_end(int32_t *tags, float *ms, int32_t max) {
+    g_probe.on = false;
+    const int n = (int)g_probe.used;
+    if (n > 0) {
+        hipError_t e = hipEventSynchronize(g_probe.pool[n - 1].b);
+        if (e != hipSuccess) return -(int)e - 1000;
+    }
+    for (int i = 0; i < n && i < max; ++i) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_probe.pool[i].a, g_probe.pool[i].b);
+        if (tags) tags[i] = g_probe.pool[i].tag;
+        if (ms) ms[i] = t;
+    }
+    return n;
+}
 
 extern "C" int gmc_version(void) { return GMC_VERSION; }
 

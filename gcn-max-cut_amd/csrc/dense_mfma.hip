@@ -71,6 +71,7 @@ extern "C" int gmc_dense_hw2_f32(const float *H, int64_t ldh, const float *dinv,
     if (n_rows == 0) return GMC_OK;
     DenseArgs a{H, (long)ldh, dinv, W2, Z0, n_rows, F};
     const int waves = (n_rows + 15) / 16;
+    GmcProbeScope probe(GMC_K_DENSE_MFMA, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(dense_hw2_mfma_kernel, dim3((waves + 3) / 4), dim3(256), 0,
                        static_cast<hipStream_t>(stream), a);
     GMC_LAUNCH_CHECK();

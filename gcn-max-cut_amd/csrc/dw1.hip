@@ -111,11 +111,14 @@ int gmc_dw1_launch(const gmc_batch *b, const float *U, long ldu, float *dW1, flo
     const int chunks = gmc_dw1_chunks(b->B);
     Dw1Args a{*b, U, ldu, chunks > 1 ? scratch : dW1, N, F, (b->B + chunks - 1) / chunks};
     dim3 grid((N + 3) / 4, chunks);
+    gmc_probe_mark(GMC_K_DW1, true, st);
     if (F <= 256) hipLaunchKernelGGL(dw1_gather_kernel<1>, grid, dim3(256), 0, st, a);
     else if (F <= 512) hipLaunchKernelGGL(dw1_gather_kernel<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(dw1_gather_kernel<4>, grid, dim3(256), 0, st, a);
+    gmc_probe_mark(GMC_K_DW1, false, st);
     GMC_LAUNCH_CHECK();
     if (chunks > 1) {
+        GmcProbeScope probe(GMC_K_DW1_FOLD, st);
         const long n4 = (long)N * F / 4;
         const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
         hipLaunchKernelGGL(fold_chunks_kernel, dim3(blocks), dim3(256), 0, st,

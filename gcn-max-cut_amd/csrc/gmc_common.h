@@ -13,6 +13,21 @@
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// Optional per-kernel timing (bench.py): hipEvents recorded around each launch of the fused
+// step on the caller's stream.  Off by default (no events, capture-safe).
+void gmc_probe_mark(int tag, bool begin, hipStream_t st);
+struct GmcProbeScope {
+    int tag; hipStream_t st;
+    GmcProbeScope(int t, hipStream_t s) : tag(t), st(s) { gmc_probe_mark(tag, true, st); }
+    ~GmcProbeScope() { gmc_probe_mark(tag, false, st); }
+};
+
+// internal form of gmc_spmm_f32 with a probe tag (variant 1 = shared-source W1 gather)
+int gmc_spmm_launch(const int32_t *rowptr, const int32_t *col, const float *vals, const float *scale,
+                    const float *X, int64_t ldx, const float *bias, int relu, float *Y, int64_t ldy,
+                    int32_t n_rows, int32_t F, int32_t group_rows, const float *W2, float *Z0,
+                    int tag, hipStream_t st);
+
 static inline bool gmc_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 namespace gmc {

@@ -203,6 +203,12 @@ extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, const float
     if (batch->B == 0) return GMC_OK;
     HeadArgs a{*batch, Z0, b2, C, P, S, loss, GY2, db2part};
     const size_t lds = sizeof(float) * (7 * (size_t)batch->n_max + 64);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    GmcProbeScope probe(GMC_K_HEAD, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(head_kernel, dim3(batch->B), dim3(kHeadThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     GMC_LAUNCH_CHECK();
@@ -217,6 +223,7 @@ int gmc_head_bwd_launch(const gmc_batch *batch, const float *P, const float *GP,
     if (batch->B == 0) return GMC_OK;
     HeadBwdArgs a{*batch, P, GP, GY2, db2part};
     const size_t lds = sizeof(float) * (3 * (size_t)batch->n_max + 64);
+    GmcProbeScope probe(GMC_K_HEAD, st);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(batch->B), dim3(kHeadThreads), lds, st, a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;

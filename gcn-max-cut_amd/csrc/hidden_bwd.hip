@@ -138,6 +138,7 @@ int gmc_hidden_bwd_launch(const float *H, long ldh, const float *GY2, const floa
     if (R == 0) return GMC_OK;
     HiddenArgs a{H, ldh, GY2, W2, dinv, Gs, ldg, part, R, F};
     dim3 grid(gmc_hidden_tiles(R), (F / 4 + kColThreads - 1) / kColThreads);
+    GmcProbeScope probe(GMC_K_HIDDEN_BWD, st);
     hipLaunchKernelGGL(hidden_bwd_kernel, grid, dim3(kColThreads * kRowLanes), 0, st, a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;
@@ -147,6 +148,7 @@ int gmc_colsum_reduce_launch(const float *part, int tiles, int F, float *dW2, fl
                              const float *db2part, int B, float *db2, hipStream_t st) {
     ReduceArgs a{part, tiles, F, dW2, db1, db2part, B, db2};
     const int grid = (F + kRedCols - 1) / kRedCols + 1;
+    GmcProbeScope probe(GMC_K_COLSUM, st);
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3(grid), dim3(kRedCols * kRedLanes), 0, st, a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;

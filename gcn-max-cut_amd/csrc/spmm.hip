@@ -88,7 +88,9 @@ __device__ __forceinline__ void gather_rows(const SpmmArgs &a, int myc, float my
 }
 
 // NP = number of 256-column passes a lane covers (F <= 256*NP); RPW = rows per wave.
-template <int NP, int RPW, bool HAS_VAL, bool EPI>
+// VARIANT only names the instantiation (0 = aggregation over the batch, 1 = gather from the
+// shared W1) so profilers report the two uses of the kernel separately.
+template <int NP, int RPW, bool HAS_VAL, bool EPI, int VARIANT>
 __global__ __launch_bounds__(256) void spmm_rows_v4(SpmmArgs a) {
     const int lane = gmc::lane_id();
     const int wave = gmc::uniform((int)(threadIdx.x >> 6));
@@ -205,37 +207,44 @@ __global__ __launch_bounds__(256) void spmm_rows_scalar(SpmmArgs a) {
     }
 }
 
-template <int NP>
+template <int NP, int VARIANT>
 int launch_v4(const SpmmArgs &a, hipStream_t st) {
     const int grid = (a.n_rows + kRowsPerWg - 1) / kRowsPerWg;
     const bool hv = a.vals != nullptr, epi = a.Z0 != nullptr;
     if (hv) {
-        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, true>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, false>), dim3(grid), dim3(256), 0, st, a);
+        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, true, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, false, VARIANT>), dim3(grid), dim3(256), 0, st, a);
     } else {
-        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, true>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, false>), dim3(grid), dim3(256), 0, st, a);
+        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, true, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, false, VARIANT>), dim3(grid), dim3(256), 0, st, a);
     }
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }
 
+template <int VARIANT>
+int launch_np(const SpmmArgs &a, hipStream_t st) {
+    if (a.F <= 256) return launch_v4<1, VARIANT>(a, st);
+    if (a.F <= 512) return launch_v4<2, VARIANT>(a, st);
+    return launch_v4<4, VARIANT>(a, st);
+}
+
 }  // namespace
 
-extern "C" int gmc_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *vals,
-                            const float *scale, const float *X, int64_t ldx, const float *bias,
-                            int relu, float *Y, int64_t ldy, int32_t n_rows, int32_t F,
-                            int32_t group_rows, const float *W2, float *Z0, gmc_stream_t stream) {
+int gmc_spmm_launch(const int32_t *rowptr, const int32_t *col, const float *vals, const float *scale,
+                    const float *X, int64_t ldx, const float *bias, int relu, float *Y, int64_t ldy,
+                    int32_t n_rows, int32_t F, int32_t group_rows, const float *W2, float *Z0,
+                    int tag, hipStream_t st) {
     if (!rowptr || !col || !X || !Y) return GMC_ERR_NULL;
     if (n_rows < 0 || F <= 0 || ldx < F || ldy < F) return GMC_ERR_SHAPE;
     if ((W2 == nullptr) != (Z0 == nullptr)) return GMC_ERR_NULL;
     if (n_rows == 0) return GMC_OK;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     SpmmArgs a{rowptr, col, vals, scale, X, (long)ldx, bias, relu, Y, (long)ldy,
                n_rows, F, 0, W2, Z0};
     if (group_rows > 0) a.group_wgs = (group_rows + kRowsPerWg - 1) / kRowsPerWg;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gmc_aligned16(X) &&
                      gmc_aligned16(Y) && (!bias || gmc_aligned16(bias)) && F <= 1024;
+    GmcProbeScope probe(tag, st);
     if (!vec) {
         if (Z0) return GMC_ERR_UNSUPPORTED;  // callers use gmc_dense_hw2_f32 instead
         const int grid = (n_rows + kWavesPerWg - 1) / kWavesPerWg;
@@ -244,7 +253,13 @@ extern "C" int gmc_spmm_f32(const int32_t *rowptr, const int32_t *col, const flo
         GMC_LAUNCH_CHECK();
         return GMC_OK;
     }
-    if (F <= 256) return launch_v4<1>(a, st);
-    if (F <= 512) return launch_v4<2>(a, st);
-    return launch_v4<4>(a, st);
+    return tag == GMC_K_GATHER_W1 ? launch_np<1>(a, st) : launch_np<0>(a, st);
+}
+
+extern "C" int gmc_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *vals,
+                            const float *scale, const float *X, int64_t ldx, const float *bias,
+                            int relu, float *Y, int64_t ldy, int32_t n_rows, int32_t F,
+                            int32_t group_rows, const float *W2, float *Z0, gmc_stream_t stream) {
+    return gmc_spmm_launch(rowptr, col, vals, scale, X, ldx, bias, relu, Y, ldy, n_rows, F,
+                           group_rows, W2, Z0, GMC_K_SPMM_USER, static_cast<hipStream_t>(stream));
 }

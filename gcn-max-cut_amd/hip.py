@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_PKG, "lib", "libgcnmaxcut_hip.so")
 SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
-    "gmc_backward_from_gp",
+    "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -62,6 +62,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_forward.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), f32, vp, sz, vp, vp, vp, vp]
     lib.gmc_train_fwd_bwd.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), f32, vp, sz, vp, vp, vp, vp, vp]
     lib.gmc_backward_from_gp.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), vp, sz, vp, vp, vp, vp]
+    lib.gmc_probe_begin.argtypes = [i32]
+    lib.gmc_probe_end.argtypes = [vp, vp, i32]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes"):
@@ -114,3 +116,28 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+KERNEL_TAGS = ("gather_w1", "agg_fwd", "head", "hidden_bwd", "colsum", "agg_bwd", "dw1", "dw1_fold",
+               "adam", "spmm_user", "dense_mfma")
+
+
+class Probe:
+    """``with Probe(capacity) as p: ...`` then ``p.records`` = [(kernel_tag, ms), ...]:
+    per-launch HIP-event timings recorded by the library on the launch stream."""
+
+    def __init__(self, capacity: int):
+        self.capacity, self.records = capacity, []
+
+    def __enter__(self):
+        check(load().gmc_probe_begin(self.capacity), "gmc_probe_begin")
+        return self
+
+    def __exit__(self, *exc):
+        tags = (C.c_int32 * self.capacity)()
+        ms = (C.c_float * self.capacity)()
+        n = load().gmc_probe_end(tags, ms, self.capacity)
+        if n < 0:
+            raise RuntimeError(f"gmc_probe_end failed ({n})")
+        self.records = [(KERNEL_TAGS[tags[i]], float(ms[i])) for i in range(min(n, self.capacity))]
+        return False

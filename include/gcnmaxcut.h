@@ -74,6 +74,29 @@ typedef struct gmc_model {
 int gmc_version(void);
 const char *gmc_error_string(int code);
 
+/* Kernel tags reported by the timing probe (one per launch of the fused step). */
+enum {
+    GMC_K_GATHER_W1 = 0,  /* (X o dinv) @ W1 as a row gather of W1          TrainingNeural.py:80 */
+    GMC_K_AGG_FWD = 1,    /* layer-1 aggregation + b1 + relu (+ fused H@W2)  :80-83 */
+    GMC_K_HEAD = 2,       /* per-graph [n,3] head: softmax, decode, loss, GY2 :83-106,:154-176 */
+    GMC_K_HIDDEN_BWD = 3, /* dW2/db1 partials + Gs                           backward of :81-83 */
+    GMC_K_COLSUM = 4,     /* fold of the partials, db2 */
+    GMC_K_AGG_BWD = 5,    /* conv1 backward aggregation                      backward of :80 */
+    GMC_K_DW1 = 6,        /* dW1 gather-reduce over graphs */
+    GMC_K_DW1_FOLD = 7,   /* fold of the dW1 chunk partials */
+    GMC_K_ADAM = 8,       /* fused Adam                                      :386 */
+    GMC_K_SPMM_USER = 9,  /* gmc_spmm_f32 called directly */
+    GMC_K_DENSE_MFMA = 10,
+    GMC_K_COUNT = 11
+};
+
+/* Timing probe for bench.py: between gmc_probe_begin and gmc_probe_end every kernel launch
+ * of this library is bracketed by hipEventRecord on the stream it is launched on.
+ * gmc_probe_end synchronises on the last event and returns the number of launches seen,
+ * writing up to `max` (tag, milliseconds) pairs (host pointers). */
+int gmc_probe_begin(int32_t capacity);
+int gmc_probe_end(int32_t *tags, float *ms, int32_t max);
+
 /* ---- building blocks (each is also used by the fused entry points below) ---------- */
 
 /* Y[r,:] = act( scale[r] * sum_{e in row r} vals[e] * X[col[e],:] + bias ),  r < n_rows.
