@@ -1,6 +1,7 @@
 // C-ABI orchestration: the fused forward / training entry points of gcnmaxcut.h.
 // Everything is enqueued on the caller's stream; nothing allocates or synchronises.
 #include "gmc_common.h"
+#include <stdlib.h>
 
 // launchers defined in the kernel files
 int gmc_head_bwd_launch(const gmc_batch *, const float *, const float *, float *, float *, hipStream_t);
@@ -9,21 +10,39 @@ int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, con
                           long, float *, int, int, hipStream_t);
 int gmc_colsum_reduce_launch(const float *, int, int, float *, float *, const float *, int, float *,
                              hipStream_t);
-int gmc_dw1_chunks(int B);
-int gmc_dw1_launch(const gmc_batch *, const float *, long, float *, float *, int, int, hipStream_t);
+size_t gmc_dw1_scratch_floats(const gmc_batch *b, int N, int F, bool lds);
+int gmc_dw1_launch(const gmc_batch *, const float *, long, float *, float *, int, int, bool, hipStream_t);
+bool gmc_lds_fits(const gmc_batch *b);
+int gmc_lds_groups(const gmc_batch *b, int F);
+int gmc_spmm_lds_launch(const gmc_batch *, const float *, long, int, int, const float *, const float *, int,
+                        float *, long, int, const float *, float *, int, hipStream_t);
 
 namespace {
 
 struct Workspace {
-    float *T0;       // [R,F]  (X o dinv)@W1, later Gs = dinv o Gpre
-    float *H;        // [R,F]  relu(conv1), later U = dinv o (A @ Gs)
-    float *Z0;       // [R,3]
+    long ld;         // leading dimension of the [R,F] buffers: F rounded up to 32 floats so every
+                     // row (and every 128 B column slice of it) starts on a 128 B boundary
+    int zparts;      // partials in Z0 (LDS path: one per slice group)
+    float *T0;       // [R,ld]  (X o dinv)@W1, later Gs = dinv o Gpre
+    float *H;        // [R,ld]  relu(conv1), later U = dinv o (A @ Gs)
+    float *Z0;       // [zparts,R,3]
     float *GY2;      // [R,3]
     float *part;     // [tiles,F,4]
     float *db2part;  // [B,3]
     float *dw1part;  // [chunks,N,F]
     size_t bytes;
 };
+
+// GMC_SPMM_ALGO=rows|lds forces one SpMM implementation (A/B runs recorded under profiles/);
+// default: LDS-staged tiles whenever the largest graph fits a CU's LDS.
+bool use_lds(const gmc_batch *b) {
+    static const int forced = [] {
+        const char *e = getenv("GMC_SPMM_ALGO");
+        return !e ? 0 : (e[0] == 'r' ? 1 : 2);
+    }();
+    if (forced == 1) return false;
+    return gmc_lds_fits(b);
+}
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -36,15 +55,16 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
         return p;
     };
     const size_t R = (size_t)b->R, F = (size_t)m->F;
-    w.T0 = take(R * F);
-    w.H = take(R * F);
-    w.Z0 = take(R * 3);
+    w.ld = (long)((F + 31) / 32 * 32);
+    w.zparts = use_lds(b) ? gmc_lds_groups(b, m->F) : 1;
+    w.T0 = take(R * w.ld);
+    w.H = take(R * w.ld);
+    w.Z0 = take((size_t)w.zparts * R * 3);
     if (training) {
         w.GY2 = take(R * 3);
         w.part = take((size_t)gmc_hidden_tiles(b->R) * F * 4);
         w.db2part = take((size_t)b->B * 3);
-        const int chunks = gmc_dw1_chunks(b->B);
-        w.dw1part = take(chunks > 1 ? (size_t)chunks * m->N * F : 0);
+        w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
     }
     w.bytes = off;
     return w;
@@ -64,15 +84,28 @@ int check(const gmc_batch *b, const gmc_model *m) {
 
 int group_rows(const gmc_batch *b) { return b->uniform_n > 0 ? b->uniform_n : b->n_max; }
 
+
+// Y = act(dinv o (A @ X) + bias) over the batch with either implementation; Z0 (optional) gets
+// the fused layer-2 feature transform (zparts partials on the LDS path).
+int aggregate(const gmc_batch *b, const float *X, float *Y, long ld, int F, const float *bias, int relu,
+              const float *W2, float *Z0, int tag, hipStream_t st) {
+    if (use_lds(b))
+        return gmc_spmm_lds_launch(b, X, ld, 0, 0, b->dinv, bias, relu, Y, ld, F, W2, Z0, tag, st);
+    return gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, X, ld, bias, relu, Y, ld, b->R, F,
+                           group_rows(b), W2, Z0, tag, st);
+}
+
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
-    const long F = m->F;
+    const int F = m->F;
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
-    int rc = gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, F,
-                             b->R, m->F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
+    int rc = use_lds(b)
+                 ? gmc_spmm_lds_launch(b, m->W1, F, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, F, nullptr, nullptr,
+                                       GMC_K_GATHER_W1, st)
+                 : gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, w.ld,
+                                   b->R, F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
     if (rc) return rc;
-    // layer 1 aggregation + bias + relu, layer 2 feature transform fused in the epilogue
-    return gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, w.T0, F, m->b1, 1, w.H, F, b->R,
-                           m->F, group_rows(b), m->W2, w.Z0, GMC_K_AGG_FWD, st);
+    // layer 1 aggregation + bias + relu with the layer 2 feature transform fused in
+    return aggregate(b, w.T0, w.H, w.ld, F, m->b1, 1, m->W2, w.Z0, GMC_K_AGG_FWD, st);
 }
 
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
@@ -80,16 +113,15 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
-    int rc = gmc_hidden_bwd_launch(w.H, F, w.GY2, m->W2, b->dinv, Gs, F, w.part, b->R, m->F, st);
+    int rc = gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
     if (rc) return rc;
     rc = gmc_colsum_reduce_launch(w.part, gmc_hidden_tiles(b->R), m->F, dW2, db1, w.db2part, b->B,
                                   db2, st);
     if (rc) return rc;
     // conv1 backward aggregation:  U = dinv o (A @ Gs)
-    rc = gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, Gs, F, nullptr, 0, U, F, b->R, m->F,
-                         group_rows(b), nullptr, nullptr, GMC_K_AGG_BWD, st);
+    rc = aggregate(b, Gs, U, w.ld, m->F, nullptr, 0, nullptr, nullptr, GMC_K_AGG_BWD, st);
     if (rc) return rc;
-    return gmc_dw1_launch(b, U, F, dW1, w.dw1part, m->N, m->F, st);
+    return gmc_dw1_launch(b, U, w.ld, dW1, w.dw1part, m->N, m->F, use_lds(b), st);
 }
 
 }  // namespace
@@ -184,7 +216,7 @@ extern "C" int gmc_forward(const gmc_batch *batch, const gmc_model *model, float
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = forward_body(batch, model, w, st);
     if (rc) return rc;
-    return gmc_head_f32(batch, w.Z0, model->b2, C, P, S, loss, nullptr, nullptr, stream);
+    return gmc_head_f32(batch, w.Z0, w.zparts, model->b2, C, P, S, loss, nullptr, nullptr, stream);
 }
 
 extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C,
@@ -203,7 +235,7 @@ extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model,
     }
     rc = forward_body(batch, model, w, st);
     if (rc) return rc;
-    rc = gmc_head_f32(batch, w.Z0, model->b2, C, P, S, loss, w.GY2, w.db2part, stream);
+    rc = gmc_head_f32(batch, w.Z0, w.zparts, model->b2, C, P, S, loss, w.GY2, w.db2part, stream);
     if (rc) return rc;
     return backward_body(batch, model, w, grad, st);
 }

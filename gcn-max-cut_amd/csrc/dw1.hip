@@ -87,43 +87,71 @@ __global__ __launch_bounds__(256) void dw1_gather_kernel(Dw1Args a) {
         if (on[p]) dst[lane + 64 * p] = acc[p];
 }
 
-// dW1[i] = sum_chunk part[chunk][i]  (float4 elementwise, chunk ascending)
-__global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, float4 *out, long n4, int chunks) {
+// dW1[v][:] = v < rows ? sum_chunk part[chunk][v][:] : 0   (float4 columns, chunk ascending)
+__global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, float4 *out, int N, int rows,
+                                                          int F4, int chunks) {
+    const long n4 = (long)N * F4, live = (long)rows * F4;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        float4 s = part[i];
-        for (int c = 1; c < chunks; ++c) gmc::f4_add(s, part[(long)c * n4 + i]);
+        float4 s = gmc::f4_zero();
+        if (i < live) {
+            s = part[i];
+            for (int c = 1; c < chunks; ++c) gmc::f4_add(s, part[(long)c * live + i]);
+        }
         out[i] = s;
     }
 }
 
 }  // namespace
 
-// chunks the batch is split into for parallelism; scratch = chunks*N*F floats when > 1
-int gmc_dw1_chunks(int B) {
+bool gmc_lds_fits(const gmc_batch *b);
+int gmc_dw1_lds_launch(const gmc_batch *, const float *, long, float *, int, int, int, hipStream_t);
+
+// chunks the batch is split into for parallelism
+int gmc_dw1_chunks(int B, bool lds) {
+    if (lds) {  // (slice, chunk) workgroups: ~16-32 slices x chunks should fill 512 slots
+        int c = (B + 7) / 8;
+        if (c < 1) c = 1;
+        return c > 32 ? 32 : c;
+    }
     if (B <= 4) return 1;
     const int c = (B + 7) / 8;  // ~8 graphs per wave: 1000 rows x chunks waves
     return c > 32 ? 32 : c;
 }
 
+// floats of scratch gmc_dw1_launch needs
+size_t gmc_dw1_scratch_floats(const gmc_batch *b, int N, int F, bool lds) {
+    const int chunks = gmc_dw1_chunks(b->B, lds);
+    if (lds) return (size_t)chunks * b->n_max * F;
+    return chunks > 1 ? (size_t)chunks * N * F : 0;
+}
+
 int gmc_dw1_launch(const gmc_batch *b, const float *U, long ldu, float *dW1, float *scratch,
-                   int N, int F, hipStream_t st) {
+                   int N, int F, bool lds, hipStream_t st) {
     if (F % 4 || ldu % 4 || F > 1024) return GMC_ERR_ALIGN;
-    const int chunks = gmc_dw1_chunks(b->B);
-    Dw1Args a{*b, U, ldu, chunks > 1 ? scratch : dW1, N, F, (b->B + chunks - 1) / chunks};
-    dim3 grid((N + 3) / 4, chunks);
-    gmc_probe_mark(GMC_K_DW1, true, st);
-    if (F <= 256) hipLaunchKernelGGL(dw1_gather_kernel<1>, grid, dim3(256), 0, st, a);
-    else if (F <= 512) hipLaunchKernelGGL(dw1_gather_kernel<2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(dw1_gather_kernel<4>, grid, dim3(256), 0, st, a);
-    gmc_probe_mark(GMC_K_DW1, false, st);
-    GMC_LAUNCH_CHECK();
-    if (chunks > 1) {
-        GmcProbeScope probe(GMC_K_DW1_FOLD, st);
-        const long n4 = (long)N * F / 4;
-        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-        hipLaunchKernelGGL(fold_chunks_kernel, dim3(blocks), dim3(256), 0, st,
-                           reinterpret_cast<const float4 *>(scratch), reinterpret_cast<float4 *>(dW1), n4, chunks);
+    const int chunks = gmc_dw1_chunks(b->B, lds);
+    const int per = (b->B + chunks - 1) / chunks;
+    int rows = N;
+    if (lds) {
+        int rc = gmc_dw1_lds_launch(b, U, ldu, scratch, F, chunks, per, st);
+        if (rc) return rc;
+        rows = b->n_max;
+    } else {
+        Dw1Args a{*b, U, ldu, chunks > 1 ? scratch : dW1, N, F, per};
+        dim3 grid((N + 3) / 4, chunks);
+        gmc_probe_mark(GMC_K_DW1, true, st);
+        if (F <= 256) hipLaunchKernelGGL(dw1_gather_kernel<1>, grid, dim3(256), 0, st, a);
+        else if (F <= 512) hipLaunchKernelGGL(dw1_gather_kernel<2>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(dw1_gather_kernel<4>, grid, dim3(256), 0, st, a);
+        gmc_probe_mark(GMC_K_DW1, false, st);
         GMC_LAUNCH_CHECK();
+        if (chunks == 1) return GMC_OK;
     }
+    GmcProbeScope probe(GMC_K_DW1_FOLD, st);
+    const long n4 = (long)N * F / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(fold_chunks_kernel, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(scratch), reinterpret_cast<float4 *>(dW1), N, rows,
+                       F / 4, chunks);
+    GMC_LAUNCH_CHECK();
     return GMC_OK;
 }

@@ -20,6 +20,7 @@ constexpr int kHeadThreads = 1024;
 struct HeadArgs {
     gmc_batch b;
     const float *Z0;
+    int zparts;
     const float *b2;
     float C;
     float *P;
@@ -61,7 +62,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     float *red = lds + 7 * a.b.n_max;         // [64]
     const bool train = a.GY2 != nullptr;
 
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) sA[i] = a.Z0[(long)r0 * 3 + i];
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
+        float z = a.Z0[(long)r0 * 3 + i];
+        for (int p = 1; p < a.zparts; ++p) z += a.Z0[((long)p * a.b.R + r0) * 3 + i];
+        sA[i] = z;
+    }
     __syncthreads();
 
     // phase 1: aggregate, bias, softmax, override, argmax
@@ -193,15 +198,16 @@ int check_batch(const gmc_batch *b) {
 
 }  // namespace
 
-extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, const float *b2, float C,
-                            float *P, int32_t *S, float *loss, float *GY2, float *db2part,
+extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2,
+                            float C, float *P, int32_t *S, float *loss, float *GY2, float *db2part,
                             gmc_stream_t stream) {
     int rc = check_batch(batch);
     if (rc) return rc;
     if (!Z0 || !b2 || !P) return GMC_ERR_NULL;
+    if (z_parts < 1) return GMC_ERR_SHAPE;
     if (GY2 && !db2part) return GMC_ERR_NULL;
     if (batch->B == 0) return GMC_OK;
-    HeadArgs a{*batch, Z0, b2, C, P, S, loss, GY2, db2part};
+    HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part};
     const size_t lds = sizeof(float) * (7 * (size_t)batch->n_max + 64);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),

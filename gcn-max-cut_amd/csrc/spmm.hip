@@ -18,12 +18,14 @@
 //     workgroup-chunks (= one graph of the block-diagonal batch) are given to ONE XCD
 //     so the 7x neighbour re-reads of a graph hit that XCD's 4 MiB L2.
 #include "gmc_common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
-constexpr int kRowsPerWave = 2;  // 8 rows per workgroup: 125 workgroups per n=1000 graph
 constexpr int kWavesPerWg = 4;
-constexpr int kRowsPerWg = kRowsPerWave * kWavesPerWg;
+// defaults (tuned on MI355X, see profiles/): rows per wave, neighbour rows in flight, nt stores
+constexpr int kRowsPerWave = 2;  // 8 rows per workgroup: 125 workgroups per n=1000 graph
 constexpr int kUnroll = 8;
 
 struct SpmmArgs {
@@ -55,7 +57,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg, int G) {
 
 // One neighbour batch of a row: all lane->SGPR broadcasts first, then up to kUnroll
 // row gathers in flight, then the adds in CSR order.
-template <int NP, bool HAS_VAL>
+template <int NP, int kUnroll, bool HAS_VAL>
 __device__ __forceinline__ void gather_rows(const SpmmArgs &a, int myc, float myv, int j, int cnt,
                                             const int (&cc)[NP], float4 (&acc)[NP]) {
     float4 x[kUnroll][NP];
@@ -90,7 +92,7 @@ __device__ __forceinline__ void gather_rows(const SpmmArgs &a, int myc, float my
 // NP = number of 256-column passes a lane covers (F <= 256*NP); RPW = rows per wave.
 // VARIANT only names the instantiation (0 = aggregation over the batch, 1 = gather from the
 // shared W1) so profilers report the two uses of the kernel separately.
-template <int NP, int RPW, bool HAS_VAL, bool EPI, int VARIANT>
+template <int NP, int RPW, int kUnroll, bool HAS_VAL, bool EPI, bool NT, int VARIANT>
 __global__ __launch_bounds__(256) void spmm_rows_v4(SpmmArgs a) {
     const int lane = gmc::lane_id();
     const int wave = gmc::uniform((int)(threadIdx.x >> 6));
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void spmm_rows_v4(SpmmArgs a) {
 
         const int cnt0 = min(64, end - beg);
 #pragma unroll 1
-        for (int j = 0; j < cnt0; j += kUnroll) gather_rows<NP, HAS_VAL>(a, myc[i], myv[i], j, cnt0, cc, acc);
+        for (int j = 0; j < cnt0; j += kUnroll) gather_rows<NP, kUnroll, HAS_VAL>(a, myc[i], myv[i], j, cnt0, cc, acc);
 #pragma unroll 1
         for (int e0 = beg + 64; e0 < end; e0 += 64) {  // rows with more than 64 neighbours
             const int cnt = min(64, end - e0);
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void spmm_rows_v4(SpmmArgs a) {
             float v2 = 1.f;
             if (HAS_VAL) v2 = lane < cnt ? a.vals[e0 + lane] : 0.f;
 #pragma unroll 1
-            for (int j = 0; j < cnt; j += kUnroll) gather_rows<NP, HAS_VAL>(a, c2, v2, j, cnt, cc, acc);
+            for (int j = 0; j < cnt; j += kUnroll) gather_rows<NP, kUnroll, HAS_VAL>(a, c2, v2, j, cnt, cc, acc);
         }
 
         const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale), i));
@@ -169,7 +171,16 @@ __global__ __launch_bounds__(256) void spmm_rows_v4(SpmmArgs a) {
                 y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
                 y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
             }
-            if (on[p]) reinterpret_cast<float4 *>(a.Y + (long)r * a.ldy)[lane + 64 * p] = y;
+            if (on[p]) {
+                float4 *dst = reinterpret_cast<float4 *>(a.Y + (long)r * a.ldy) + lane + 64 * p;
+                if (NT) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    v4f t = {y.x, y.y, y.z, y.w};
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(dst));
+                } else {
+                    *dst = y;
+                }
+            }
             if (EPI) {  // masked lanes carry w2 = 0
                 z0 += y.x * w2[p][0] + y.y * w2[p][3] + y.z * w2[p][6] + y.w * w2[p][9];
                 z1 += y.x * w2[p][1] + y.y * w2[p][4] + y.z * w2[p][7] + y.w * w2[p][10];
@@ -207,26 +218,51 @@ __global__ __launch_bounds__(256) void spmm_rows_scalar(SpmmArgs a) {
     }
 }
 
-template <int NP, int VARIANT>
-int launch_v4(const SpmmArgs &a, hipStream_t st) {
-    const int grid = (a.n_rows + kRowsPerWg - 1) / kRowsPerWg;
+template <int NP, int RPW, int UNR, bool NT, int VARIANT>
+int launch_cfg(SpmmArgs a, int group_rows, hipStream_t st) {
+    constexpr int rows_per_wg = RPW * kWavesPerWg;
+    const int grid = (a.n_rows + rows_per_wg - 1) / rows_per_wg;
+    a.group_wgs = group_rows > 0 ? (group_rows + rows_per_wg - 1) / rows_per_wg : 0;
     const bool hv = a.vals != nullptr, epi = a.Z0 != nullptr;
     if (hv) {
-        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, true, VARIANT>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, true, false, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, RPW, UNR, true, true, NT, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((spmm_rows_v4<NP, RPW, UNR, true, false, NT, VARIANT>), dim3(grid), dim3(256), 0, st, a);
     } else {
-        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, true, VARIANT>), dim3(grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((spmm_rows_v4<NP, kRowsPerWave, false, false, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        if (epi) hipLaunchKernelGGL((spmm_rows_v4<NP, RPW, UNR, false, true, NT, VARIANT>), dim3(grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((spmm_rows_v4<NP, RPW, UNR, false, false, NT, VARIANT>), dim3(grid), dim3(256), 0, st, a);
     }
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }
 
+// GMC_SPMM_TUNE="rpw,unroll,nt" selects a tuning variant (F in (256,512], aggregation use);
+// read once.  Only for the sweeps recorded under profiles/: production uses the default.
+struct Tune { int rpw = 0, unr = 0, nt = 0; };
+const Tune &tune() {
+    static Tune t = [] {
+        Tune v;
+        if (const char *e = getenv("GMC_SPMM_TUNE")) sscanf(e, "%d,%d,%d", &v.rpw, &v.unr, &v.nt);
+        return v;
+    }();
+    return t;
+}
+
 template <int VARIANT>
-int launch_np(const SpmmArgs &a, hipStream_t st) {
-    if (a.F <= 256) return launch_v4<1, VARIANT>(a, st);
-    if (a.F <= 512) return launch_v4<2, VARIANT>(a, st);
-    return launch_v4<4, VARIANT>(a, st);
+int launch_np(const SpmmArgs &a, int group_rows, hipStream_t st) {
+    if (a.F <= 256) return launch_cfg<1, kRowsPerWave, kUnroll, false, VARIANT>(a, group_rows, st);
+    if (a.F <= 512) {
+        if (VARIANT == 0 && tune().rpw) {
+            const Tune &t = tune();
+#define GMC_TUNE_CASE(R, U, N) \
+    if (t.rpw == R && t.unr == U && t.nt == N) return launch_cfg<2, R, U, N != 0, 0>(a, group_rows, st);
+            GMC_TUNE_CASE(1, 4, 0) GMC_TUNE_CASE(1, 8, 0) GMC_TUNE_CASE(2, 4, 0) GMC_TUNE_CASE(2, 8, 0)
+            GMC_TUNE_CASE(4, 4, 0) GMC_TUNE_CASE(4, 8, 0) GMC_TUNE_CASE(1, 4, 1) GMC_TUNE_CASE(1, 8, 1)
+            GMC_TUNE_CASE(2, 4, 1) GMC_TUNE_CASE(2, 8, 1) GMC_TUNE_CASE(4, 4, 1) GMC_TUNE_CASE(4, 8, 1)
+#undef GMC_TUNE_CASE
+        }
+        return launch_cfg<2, kRowsPerWave, kUnroll, false, VARIANT>(a, group_rows, st);
+    }
+    return launch_cfg<4, kRowsPerWave, kUnroll, false, VARIANT>(a, group_rows, st);
 }
 
 }  // namespace
@@ -241,7 +277,6 @@ int gmc_spmm_launch(const int32_t *rowptr, const int32_t *col, const float *vals
     if (n_rows == 0) return GMC_OK;
     SpmmArgs a{rowptr, col, vals, scale, X, (long)ldx, bias, relu, Y, (long)ldy,
                n_rows, F, 0, W2, Z0};
-    if (group_rows > 0) a.group_wgs = (group_rows + kRowsPerWg - 1) / kRowsPerWg;
     const bool vec = (F % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gmc_aligned16(X) &&
                      gmc_aligned16(Y) && (!bias || gmc_aligned16(bias)) && F <= 1024;
     GmcProbeScope probe(tag, st);
@@ -253,7 +288,7 @@ int gmc_spmm_launch(const int32_t *rowptr, const int32_t *col, const float *vals
         GMC_LAUNCH_CHECK();
         return GMC_OK;
     }
-    return tag == GMC_K_GATHER_W1 ? launch_np<1>(a, st) : launch_np<0>(a, st);
+    return tag == GMC_K_GATHER_W1 ? launch_np<1>(a, group_rows, st) : launch_np<0>(a, group_rows, st);
 }
 
 extern "C" int gmc_spmm_f32(const int32_t *rowptr, const int32_t *col, const float *vals,

@@ -189,7 +189,8 @@ class GraphBatch:
         self.vals = None if vals is None else dev(vals)
         self.dinv = dev(dinv)
         self.c = hip.GmcBatch(
-            B=self.B, R=self.R, nnz=self.nnz, n_max=self.n_max, uniform_n=self.uniform_n, reserved=0,
+            B=self.B, R=self.R, nnz=self.nnz, n_max=self.n_max, uniform_n=self.uniform_n,
+            nnz_max=int(nnzs.max()) if B else 0,
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
             lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv))
 

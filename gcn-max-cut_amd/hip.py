@@ -32,7 +32,7 @@ class HipExtensionError(RuntimeError):
 class GmcBatch(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("R", C.c_int32), ("nnz", C.c_int32), ("n_max", C.c_int32),
-        ("uniform_n", C.c_int32), ("reserved", C.c_int32),
+        ("uniform_n", C.c_int32), ("nnz_max", C.c_int32),
         ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
         ("vals", C.c_void_p), ("dinv", C.c_void_p),
     ]
@@ -55,7 +55,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_error_string.argtypes = [C.c_int]
     lib.gmc_spmm_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.gmc_dense_hw2_f32.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp]
-    lib.gmc_head_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, f32, vp, vp, vp, vp, vp, vp]
+    lib.gmc_head_f32.argtypes = [C.POINTER(GmcBatch), vp, i32, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.gmc_adam_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
     lib.gmc_workspace_bytes.restype = sz
     lib.gmc_workspace_bytes.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), C.c_int]

@@ -55,7 +55,7 @@ typedef struct gmc_batch {
     int32_t nnz;           /* total directed edges = sum 2|E_g| */
     int32_t n_max;         /* max n_g */
     int32_t uniform_n;     /* n if every graph has n nodes, else 0 (XCD grouping hint) */
-    int32_t reserved;
+    int32_t nnz_max;       /* max directed edges of one graph (sizes the LDS index cache) */
     const int32_t *goff;   /* [B+1] first row of each graph */
     const int32_t *rowptr; /* [R+1] */
     const int32_t *gcol;   /* [nnz] neighbour as batch row id  (aggregation operand) */
@@ -121,9 +121,11 @@ int gmc_dense_hw2_f32(const float *H, int64_t ldh, const float *dinv, const floa
  * rows 0,1,2 forced to e0,e1,e2 and S = row-argmax, first max wins (:87-106);
  * loss[g] = -C * cut(S) (:154-176,:291-309).  When GY2 != NULL also the start of
  * loss.backward(): GP = C*A_val@onehot(S), softmax backward, db2part[g,:] = colsum(GZ),
- * GY2 = A @ (dinv*GZ).  P [R,3], S [R], loss [B], db2part [B,3], GY2 [R,3]. */
-int gmc_head_f32(const gmc_batch *batch, const float *Z0, const float *b2, float C, float *P,
-                 int32_t *S, float *loss, float *GY2, float *db2part, gmc_stream_t stream);
+ * GY2 = A @ (dinv*GZ).  P [R,3], S [R], loss [B], db2part [B,3], GY2 [R,3].
+ * Z0 is [z_parts][R][3]: partial products of the LDS-tiled layer-1 kernel (one per column
+ * slice group), folded here in ascending order; z_parts = 1 for a plain [R,3] Z0. */
+int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2, float C,
+                 float *P, int32_t *S, float *loss, float *GY2, float *db2part, gmc_stream_t stream);
 
 /* torch.optim.Adam.step (TrainingNeural.py:337,:386) over one flat buffer, fused:
  * m,v update + bias correction + parameter update in a single sweep. step >= 1. */
