@@ -1,30 +1,40 @@
 // LDS-staged block-diagonal SpMM for gfx950 (the fast path for graphs that fit a CU's LDS).
 //
-//   Y[g][r, c0:c0+FS] = act( scale[r] * sum_{e in row r} vals[e] * X_g[lcol[e], c0:c0+FS] + bias )
+//   Y[g][r, c0:c0+FS] = act( scale[r] * sum_{e in row r} vals[e] * X_g[nbr(e), c0:c0+FS] + bias )
 //
-// One workgroup owns one graph and a group of its column slices.  It loads the graph's CSR
-// once into LDS as 16-bit indices, then per slice: (1) stages the slice of ALL of the graph's
-// source rows into LDS with coalesced, fully independent loads - every HBM byte of X is read
-// exactly once, the d-fold neighbour re-reads never leave the CU; (2) every output row
-// gathers its neighbours from LDS (ds_read_b128) and sums them in CSR order, bitwise
-// identical to the row-per-wave kernel in spmm.hip; bias / relu / row scale are fused into
-// the store.  Optionally the layer-2 feature transform (Y o scale) @ W2 (K = 3) is
-// accumulated per row across the workgroup's slices (LDS, no atomics) and written as one
-// partial per slice group; the head kernel folds the partials in fixed order.
+// One workgroup owns one graph and a group of its column slices.  It copies the graph's
+// neighbour table (ELL, 16-bit local ids, 8 or 16 slots per row, padded with the id of an
+// all-zero row) into LDS once, then per slice: (1) stages the slice of ALL of the graph's
+// source rows into LDS with coalesced, mutually independent loads - every HBM byte of X is
+// read exactly once, the d-fold neighbour re-reads never leave the CU; (2) every output row
+// reads its 8 neighbour ids with ONE ds_read_b128, gathers the 8 rows with ds_read_b128 and
+// sums them in CSR order (padding adds +0.0f), bitwise identical to the row-per-wave kernel
+// in spmm.hip; bias / relu / row scale are fused into the store.  The tile is double-buffered:
+// the loads of slice s+1 are issued into registers BEFORE the gather of slice s and are written
+// to the other LDS buffer after it (software pipeline, one barrier per slice: HBM reads
+// overlap the LDS gather and the stores).  One 1024-thread workgroup per CU.  Optionally the layer-2
+// feature transform (Y o scale) @ W2 (K = 3) is accumulated per row in registers across the
+// workgroup's slices and written as one partial per slice group; the head kernel folds the
+// partials in fixed order.
 //
 // Replaces the same reference lines as spmm.hip: DGL's update_all(copy_u,sum) inside
 // GraphConv (TrainingNeural.py:80,83), the X@W1 feature transform as a row gather of W1
 // (:373: X is the padded adjacency) and (H*outdeg^-1/2)@W2 (:83).
 //
-// A second kernel, dw1_lds_kernel, is the transposed use: dW1[v, slice] = sum over the graphs
-// of a chunk of A_val,g @ U_g - the accumulators stay in registers across graphs.
+// dw1_lds_kernel is the transposed use: dW1[v, slice] = sum over the graphs of a chunk of
+// A_val,g @ U_g - the accumulators stay in registers across graphs.
 //
-// HBM-bound by construction: bytes moved = algorithmic bytes (+ 2 B/edge of indices once per
-// slice group).  All slices of a graph run on one XCD so the indices stay in its L2.
+// HBM-bound by construction: bytes moved = algorithmic bytes (+ 2 B per neighbour slot once
+// per slice group).  All slices of a graph run on one XCD so its table stays in that L2.
 #include "gmc_common.h"
 #include <stdlib.h>
 
 namespace {
+
+constexpr int kThreads = 1024;
+#ifndef GMC_DBG
+#define GMC_DBG 0  // compile-time ablation mask for diagnostic builds: 2 no gather, 4 no store
+#endif
 
 struct TileArgs {
     gmc_batch b;
@@ -61,97 +71,111 @@ __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
     }
 }
 
-struct LdsLayout {
-    float *tile;           // [n_max][FS]
-    unsigned short *rp;    // [n_max + 1]  row offsets relative to the graph's first edge
-    unsigned short *lc;    // [nnz_max]    local neighbour ids
-};
-
-__device__ __forceinline__ LdsLayout carve_lds(float *base, int n_max, int FS) {
-    LdsLayout l;
-    l.tile = base;
-    l.rp = reinterpret_cast<unsigned short *>(base + (size_t)n_max * FS);
-    l.lc = l.rp + ((n_max + 2) & ~1);
-    return l;
+// LDS: two tiles [(n_max + 1)][FS] floats (row n = zeros, the padding target), then the
+// neighbour table [n_max][W] of 16-bit ids.
+__host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + 1) * FS; }
+constexpr int kMaxSlicesPerWg = 8;
+size_t lds_bytes(int n_max, int W, int FS) {  // + bias and W2 rows of up to kMaxSlicesPerWg slices
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (size_t)kMaxSlicesPerWg * FS * 16;
 }
 
-size_t lds_bytes(int n_max, int nnz_max, int FS) {
-    return (size_t)n_max * FS * 4 + (size_t)((n_max + 2) & ~1) * 2 + (size_t)((nnz_max + 1) & ~1) * 2;
-}
-
-// graph CSR -> LDS (16-bit); caller syncs
-template <int THREADS>
-__device__ __forceinline__ void load_indices(const gmc_batch &b, int r0, int n, const LdsLayout &L) {
-    const int e0 = b.rowptr[r0];
-    for (int i = threadIdx.x; i <= n; i += THREADS) L.rp[i] = (unsigned short)(b.rowptr[r0 + i] - e0);
-    const int nnz = b.rowptr[r0 + n] - e0;
-    for (int i = threadIdx.x; i < nnz; i += THREADS) L.lc[i] = (unsigned short)b.lcol[e0 + i];
-}
-
-// stage X[src_row0 + row, c0 + 4q .. +3] for all rows into tile[row][4q..]; idx-th float4 of
-// the tile = (row idx / Q, lane idx % Q); all loads of a thread are independent.
-template <int FS, int THREADS>
-__device__ __forceinline__ void stage_tile(const float *src_q, long ldx, int n, bool col_on, float *tile) {
-    constexpr int Q = FS / 4;
-    constexpr int kBatch = 8;
-    const int total = n * Q;
-    for (int base = threadIdx.x; base < total; base += THREADS * kBatch) {
-        float4 v[kBatch];
+// thread t owns float4 #(t + k*kThreads) of the tile = (row lrow + k*rows_per_pass, lane q):
+// exactly the (row, lane) pairs it later produces, so ACC registers hold one slice of them.
+template <int FS, int ACC>
+__device__ __forceinline__ void prefetch_tile(const float *src_q, long ldx, int n, bool col_on, int lrow,
+                                              float4 (&pf)[ACC]) {
+    constexpr int kRowsPerPass = kThreads / (FS / 4);
 #pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int idx = base + k * THREADS;
-            v[k] = gmc::f4_zero();
-            if (idx < total && col_on) v[k] = *reinterpret_cast<const float4 *>(src_q + (long)(idx / Q) * ldx);
-        }
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-            const int idx = base + k * THREADS;
-            if (idx < total) reinterpret_cast<float4 *>(tile)[idx] = v[k];
-        }
+    for (int k = 0; k < ACC; ++k) {
+        const int l = lrow + k * kRowsPerPass;
+        pf[k] = gmc::f4_zero();
+        if (l < n && col_on) pf[k] = *reinterpret_cast<const float4 *>(src_q + (long)l * ldx);
     }
 }
 
-// sum over the row's neighbours, CSR order, from the LDS tile
-template <int FS, bool HAS_VAL>
-__device__ __forceinline__ float4 gather_row(const LdsLayout &L, const float *gvals, int beg, int end, int q) {
+template <int FS, int ACC>
+__device__ __forceinline__ void commit_tile(float *tile, int n, int lrow, int q, const float4 (&pf)[ACC]) {
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) {
+        const int l = lrow + k * kRowsPerPass;
+        if (l < n) reinterpret_cast<float4 *>(tile)[l * Q + q] = pf[k];
+    }
+}
+
+// graph's neighbour table -> LDS (straight 16 B copies), zero row n of both tiles; caller syncs
+template <int FS, int W>
+__device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, float *tile0, float *tile1,
+                                           unsigned short *nb) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(b.ell + (long)r0 * W);
+    const int total = n * (W / 8);
+    for (int i = threadIdx.x; i < total; i += kThreads) reinterpret_cast<uint4 *>(nb)[i] = src[i];
+    if (threadIdx.x < FS) {
+        tile0[(long)n * FS + threadIdx.x] = 0.f;
+        tile1[(long)n * FS + threadIdx.x] = 0.f;
+    }
+}
+
+// sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
+template <int FS, int W, bool HAS_VAL>
+__device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
+                                             int l, int q) {
     constexpr int Q = FS / 4;
     float4 acc = gmc::f4_zero();
-    for (int e = beg; e < end; e += 8) {
-        int c[8];
-        float w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int ee = min(e + u, end - 1);
-            c[u] = L.lc[ee];
-            if (HAS_VAL) w[u] = gvals[ee];
-        }
+    for (int blk = 0; blk < W / 8; ++blk) {
+        const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
+        const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
+                                ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+        float4 x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (e + u < end) {
-                const float4 x = reinterpret_cast<const float4 *>(L.tile)[c[u] * Q + q];
-                if (HAS_VAL) gmc::f4_fma(acc, w[u], x);
-                else gmc::f4_add(acc, x);
-            }
+        for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[u] * Q + q];
+        if (HAS_VAL) {  // weights come from HBM/L2: this (rare) variant waits on them per row
+            const float4 w0 = *reinterpret_cast<const float4 *>(wrow + blk * 8);
+            const float4 w1 = *reinterpret_cast<const float4 *>(wrow + blk * 8 + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
         }
     }
     return acc;
 }
 
-// ACC = rows per thread (ACC * rows-per-pass >= n_max): the per-row scale factors and, with
-// EPI, the fused-W2 partial sums of a thread's rows live in registers across the slices.
-template <int FS, int THREADS, bool HAS_VAL, int ACC, bool EPI>
-__global__ __launch_bounds__(THREADS, 4) void spmm_lds_kernel(TileArgs a) {
+// ACC = rows per thread (ACC * rows-per-pass >= n_max).
+//
+// Slice loop, software-pipelined so that no wait ever covers a freshly issued memory op
+// (vmcnt retires in order and __syncthreads() drains it):
+//   stores of slice s-1 (held in registers)  ->  loads of slice s+1 (into registers)  ->
+//   LDS gather of slice s  ->  wait (loads s+1 done; stores s-1 long done)  ->
+//   write slice s+1 to the other LDS buffer  ->  barrier.
+template <int FS, int W, int ACC, bool EPI, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
-    constexpr int kRowsPerPass = THREADS / Q;
+    constexpr int kRowsPerPass = kThreads / Q;
     int g, grp;
     tile_of((int)blockIdx.x, a.b.B, a.groups, g, grp);
     const int r0 = a.b.goff[g];
     const int n = a.b.goff[g + 1] - r0;
-    const LdsLayout L = carve_lds(lds, a.b.n_max, FS);
+    const int per = (a.slices + a.groups - 1) / a.groups;
+    const int s_beg = grp * per, s_end = min(a.slices, s_beg + per);
+    if (s_beg >= s_end) return;
+
+    const int TF = (int)tile_floats(a.b.n_max, FS);  // floats per tile buffer (offsets keep LDS addressing)
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
+    float *cbias = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [per*FS] bias of my columns
+    float *cw2 = cbias + per * FS;                                          // [per*FS][3] W2 rows of my columns
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
-    const int e0 = a.b.rowptr[r0];
-    const float *gvals = HAS_VAL ? a.b.vals + e0 : nullptr;
+    const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+    const float *src0 = a.X + (a.shared_src ? 0L : (long)r0 * a.ldx) + 4 * q;
+
+    float4 pf[ACC];
+    prefetch_tile<FS, ACC>(src0 + s_beg * FS, a.ldx, n, s_beg * FS + 4 * q < a.F, lrow, pf);
+
     float zr[EPI ? ACC : 1][3] = {};
     float sc[ACC];
 #pragma unroll
@@ -159,49 +183,75 @@ __global__ __launch_bounds__(THREADS, 4) void spmm_lds_kernel(TileArgs a) {
         const int l = lrow + k * kRowsPerPass;
         sc[k] = (a.scale && l < n) ? a.scale[r0 + l] : 1.0f;
     }
+    for (int i = threadIdx.x; i < per * FS; i += kThreads) {  // column constants of my slices -> LDS
+        const int c = s_beg * FS + i;
+        cbias[i] = (a.bias && c < a.F) ? a.bias[c] : 0.f;
+        if (EPI) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cw2[3 * i + j] = c < a.F ? a.W2[(long)c * 3 + j] : 0.f;
+        }
+    }
+    load_table<FS, W>(a.b, r0, n, lds, lds + TF, nb);
+    commit_tile<FS, ACC>(lds, n, lrow, q, pf);
+    __syncthreads();
 
-    load_indices<THREADS>(a.b, r0, n, L);
-
-    const int per = (a.slices + a.groups - 1) / a.groups;
-    const int s_beg = grp * per, s_end = min(a.slices, s_beg + per);
-    for (int s = s_beg; s < s_end; ++s) {
-        const int c0 = s * FS;
-        const bool col_on = c0 + 4 * q < a.F;  // ragged last slice
-        __syncthreads();                        // previous slice's readers are done with the tile
-        if (!(a.dbg & 1))
-            stage_tile<FS, THREADS>(a.X + (a.shared_src ? 0L : (long)r0 * a.ldx) + c0 + 4 * q, a.ldx, n, col_on, L.tile);
-        float4 bias = gmc::f4_zero();
-        if (a.bias && col_on) bias = *reinterpret_cast<const float4 *>(a.bias + c0 + 4 * q);
+    float4 y[ACC];
+    // gather + epilogue of slice s from tile buffer `cur` into y (and the fused-W2 partials)
+    auto compute = [&](int s, int cur) {
+        const float *tile = lds + cur * TF;
+        const int cl = (s - s_beg) * FS + 4 * q;
+        const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
         float w2[EPI ? 12 : 1];
         if (EPI) {
 #pragma unroll
-            for (int j = 0; j < 12; ++j) w2[j] = col_on ? a.W2[(long)(c0 + 4 * q) * 3 + j] : 0.f;
+            for (int j = 0; j < 12; ++j) w2[j] = cw2[3 * cl + j];
         }
-        __syncthreads();
-
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = min(lrow + k * kRowsPerPass, n - 1);  // rows past the end redo row n-1 (never stored)
+            float4 acc = gmc::f4_zero();
+            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
+            y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
+            if (a.relu) {
+                y[k].x = y[k].x > 0.f ? y[k].x : 0.f; y[k].y = y[k].y > 0.f ? y[k].y : 0.f;
+                y[k].z = y[k].z > 0.f ? y[k].z : 0.f; y[k].w = y[k].w > 0.f ? y[k].w : 0.f;
+            }
+            if (EPI) {  // columns past F carry w2 = 0
+                zr[k][0] += y[k].x * w2[0] + y[k].y * w2[3] + y[k].z * w2[6] + y[k].w * w2[9];
+                zr[k][1] += y[k].x * w2[1] + y[k].y * w2[4] + y[k].z * w2[7] + y[k].w * w2[10];
+                zr[k][2] += y[k].x * w2[2] + y[k].y * w2[5] + y[k].z * w2[8] + y[k].w * w2[11];
+            }
+        }
+    };
+    auto store = [&](int s) {
+        const int c = s * FS + 4 * q;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            if (l < n) {
-                float4 acc = gmc::f4_zero();
-                if (!(a.dbg & 2)) acc = gather_row<FS, HAS_VAL>(L, gvals, L.rp[l], L.rp[l + 1], q);
-                float4 y;
-                y.x = fmaf(acc.x, sc[k], bias.x); y.y = fmaf(acc.y, sc[k], bias.y);
-                y.z = fmaf(acc.z, sc[k], bias.z); y.w = fmaf(acc.w, sc[k], bias.w);
-                if (a.relu) {
-                    y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
-                    y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
-                }
-                if (col_on && !(a.dbg & 4)) *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.ldy + c0 + 4 * q) = y;
-                if (EPI) {  // masked lanes carry w2 = 0
-                    zr[k][0] += y.x * w2[0] + y.y * w2[3] + y.z * w2[6] + y.w * w2[9];
-                    zr[k][1] += y.x * w2[1] + y.y * w2[4] + y.z * w2[7] + y.w * w2[10];
-                    zr[k][2] += y.x * w2[2] + y.y * w2[5] + y.z * w2[8] + y.w * w2[11];
-                }
-            }
-            if (EPI) __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps VGPRs under 128
+            if (l < n && c < a.F && !(GMC_DBG & 4)) *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.ldy + c) = y[k];
         }
+    };
+    auto prefetch = [&](int s) {  // clamped: past the last slice re-read it (L2 hit, never used)
+        const int c = min(s, s_end - 1) * FS;
+        prefetch_tile<FS, ACC>(src0 + c, a.ldx, n, c + 4 * q < a.F, lrow, pf);
+    };
+
+    // peeled first slice, then a branch-free steady state
+    prefetch(s_beg + 1);
+    compute(s_beg, 0);
+    commit_tile<FS, ACC>(lds + TF, n, lrow, q, pf);
+    __syncthreads();
+    for (int s = s_beg + 1; s < s_end; ++s) {
+        const int cur = (s - s_beg) & 1;
+        prefetch(s + 1);   // loads of the next slice: in flight during the gather below
+        store(s - 1);      // stores of the previous slice: complete during the gather below
+        asm volatile("" ::: "memory");  // keep every load and store above ahead of the gather
+        compute(s, cur);
+        commit_tile<FS, ACC>(lds + (cur ^ 1) * TF, n, lrow, q, pf);
+        __syncthreads();   // next tile complete; everyone is done reading this one
     }
+    store(s_end - 1);
     if (EPI) {  // fold the row's Q lanes (fixed xor tree), one partial per slice group
         float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
@@ -231,39 +281,71 @@ struct Dw1TileArgs {
     int graphs_per_chunk;
 };
 
-template <int FS, int THREADS, int ACC, bool HAS_VAL>
-__global__ __launch_bounds__(THREADS, 4) void dw1_lds_kernel(Dw1TileArgs a) {
+template <int FS, int W, int ACC, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
-    constexpr int kRowsPerPass = THREADS / Q;
-    // chunk-major in XCD order: blocks of one chunk (all its slices) share an XCD
-    int chunk, s;
+    constexpr int kRowsPerPass = kThreads / Q;
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
+    int chunk, s;  // chunk-major in XCD order: the slices of one chunk share an XCD
     tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
-    const LdsLayout L = carve_lds(lds, a.b.n_max, FS);
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const int c0 = s * FS;
     const bool col_on = c0 + 4 * q < a.F;
-    float4 acc[ACC];
+    float4 acc[ACC], pf[ACC];
+    uint4 pt[NT];
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = gmc::f4_zero();
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
-    for (int g = g0; g < g1; ++g) {
+    if (g0 >= g1) return;
+    auto fetch = [&](int g) {  // tile slice + neighbour table of graph g -> registers
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
-        const int e0 = a.b.rowptr[r0];
-        __syncthreads();
-        load_indices<THREADS>(a.b, r0, n, L);
-        stage_tile<FS, THREADS>(a.U + (long)r0 * a.ldu + c0 + 4 * q, a.ldu, n, col_on, L.tile);
-        __syncthreads();
+        prefetch_tile<FS, ACC>(a.U + (long)r0 * a.ldu + c0 + 4 * q, a.ldu, n, col_on, lrow, pf);
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit_table = [&](int n) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+        }
+    };
+    fetch(g0);
+    {
+        const int n = a.b.goff[g0 + 1] - a.b.goff[g0];
+        commit_tile<FS, ACC>(lds, n, lrow, q, pf);
+        commit_table(n);
+        if (threadIdx.x < FS) lds[n * FS + threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    for (int g = g0; g < g1; ++g) {
+        const int cur = (g - g0) & 1;
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
+        if (g + 1 < g1) fetch(g + 1);
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            if (l < n) {
-                const float4 t = gather_row<FS, HAS_VAL>(L, HAS_VAL ? a.b.vals + e0 : nullptr, L.rp[l], L.rp[l + 1], q);
-                gmc::f4_add(acc[k], t);
-            }
+            if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(lds + cur * TF, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
         }
+        if (g + 1 < g1) {
+            const int n1 = a.b.goff[g + 2] - a.b.goff[g + 1];
+            commit_tile<FS, ACC>(lds + (cur ^ 1) * TF, n1, lrow, q, pf);
+            if (threadIdx.x < FS) lds[(cur ^ 1) * TF + n1 * FS + threadIdx.x] = 0.f;
+            __syncthreads();  // everyone is done with graph g's table
+            commit_table(n1);
+        }
+        __syncthreads();
     }
     if (col_on) {
 #pragma unroll
@@ -274,82 +356,77 @@ __global__ __launch_bounds__(THREADS, 4) void dw1_lds_kernel(Dw1TileArgs a) {
     }
 }
 
-struct Shape { int fs, threads; };
-
-// Slice width / workgroup size for graphs of up to n_max nodes and nnz_max edges.
-// Preferred: the widest slice whose tile + indices fit 80 KiB, so two 512-thread workgroups
-// share a CU and one stages while the other gathers; else one 1024-thread workgroup per CU.
-Shape pick_shape(int n_max, int nnz_max) {
-    if (n_max > 65535 || nnz_max > 65535) return {0, 0};
+// Slice width for graphs of up to n_max nodes with W neighbour slots: the widest slice whose
+// two tile buffers + table fit the CU's 160 KiB of LDS; 0 = does not fit (row kernels).
+int pick_fs(int n_max, int W) {
+    if (n_max >= 65535 || (W != 8 && W != 16)) return 0;
     for (int fs = 64; fs >= 16; fs >>= 1)
-        if (lds_bytes(n_max, nnz_max, fs) <= 80 * 1024) return {fs, 512};
-    for (int fs = 32; fs >= 8; fs >>= 1)
-        if (lds_bytes(n_max, nnz_max, fs) <= 160 * 1024) return {fs, 1024};
-    return {0, 0};
+        if (lds_bytes(n_max, W, fs) <= 160 * 1024) return fs;
+    return 0;
 }
 
-template <int FS, int THREADS>
+template <typename K, typename A>
+int launch(K k, int grid, size_t lds, hipStream_t st, const A &args) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, args);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
+template <int FS, int W>
 int launch_spmm(const TileArgs &a, size_t lds, hipStream_t st) {
-    const int grid = a.b.B * a.groups;
-    constexpr int rows_per_pass = THREADS / (FS / 4);
+    constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
-    if (acc > 16) return GMC_ERR_UNSUPPORTED;
-#define GMC_GO(HV, AC, EP)                                                                                 \
-    do {                                                                                                   \
-        auto k = spmm_lds_kernel<FS, THREADS, HV, AC, EP>;                                                 \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),                  \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, st, a);                                      \
+    const int grid = a.b.B * a.groups;
+    const bool epi = a.Zpart != nullptr;
+#define GMC_PICK(AC)                                                                                   \
+    do {                                                                                               \
+        if (a.use_vals) return epi ? launch(spmm_lds_kernel<FS, W, AC, true, true>, grid, lds, st, a)   \
+                                   : launch(spmm_lds_kernel<FS, W, AC, false, true>, grid, lds, st, a); \
+        return epi ? launch(spmm_lds_kernel<FS, W, AC, true, false>, grid, lds, st, a)                  \
+                   : launch(spmm_lds_kernel<FS, W, AC, false, false>, grid, lds, st, a);                \
     } while (0)
-#define GMC_GO_ACC(HV, EP)                                                                                 \
-    do {                                                                                                   \
-        if (acc <= 4) GMC_GO(HV, 4, EP); else if (acc <= 8) GMC_GO(HV, 8, EP); else GMC_GO(HV, 16, EP);    \
-    } while (0)
-    if (a.use_vals) { if (a.Zpart) GMC_GO_ACC(true, true); else GMC_GO_ACC(true, false); }
-    else { if (a.Zpart) GMC_GO_ACC(false, true); else GMC_GO_ACC(false, false); }
-#undef GMC_GO_ACC
-#undef GMC_GO
-    GMC_LAUNCH_CHECK();
-    return GMC_OK;
+    if (acc <= 4) GMC_PICK(4);
+    if (acc <= 8) GMC_PICK(8);
+#undef GMC_PICK
+    return GMC_ERR_UNSUPPORTED;
 }
 
-template <int FS, int THREADS>
+template <int FS, int W>
 int launch_dw1(const Dw1TileArgs &a, size_t lds, hipStream_t st) {
-    constexpr int rows_per_pass = THREADS / (FS / 4);
+    constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
-    if (acc > 16) return GMC_ERR_UNSUPPORTED;
     const int grid = a.slices * a.chunks;
-#define GMC_GO(HV, AC)                                                                                     \
-    do {                                                                                                   \
-        auto k = dw1_lds_kernel<FS, THREADS, AC, HV>;                                                      \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k),                  \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(THREADS), lds, st, a);                                      \
-    } while (0)
-#define GMC_GO_ACC(HV)                                                                                     \
-    do {                                                                                                   \
-        if (acc <= 4) GMC_GO(HV, 4); else if (acc <= 8) GMC_GO(HV, 8); else GMC_GO(HV, 16);                \
-    } while (0)
-    if (a.b.vals) GMC_GO_ACC(true); else GMC_GO_ACC(false);
-#undef GMC_GO_ACC
-#undef GMC_GO
-    GMC_LAUNCH_CHECK();
-    return GMC_OK;
+    const bool hv = a.b.ell_vals != nullptr;
+    if (acc <= 4) return hv ? launch(dw1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
+                            : launch(dw1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
+    if (acc <= 8) return hv ? launch(dw1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
+                            : launch(dw1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    return GMC_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-// b->nnz_max carries nnz_max (largest per-graph edge count).
-bool gmc_lds_fits(const gmc_batch *b) { return pick_shape(b->n_max, b->nnz_max).fs > 0; }
+bool gmc_lds_fits(const gmc_batch *b) {
+    if (!b->ell) return false;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    if (!fs) return false;
+    const int rows_per_pass = kThreads / (fs / 4);
+    return (b->n_max + rows_per_pass - 1) / rows_per_pass <= 8;
+}
 
-// slice groups (workgroups) per graph == number of Zpart partials of the fused W2 epilogue
+// slice groups (workgroups) per graph == number of Zpart partials of the fused W2 epilogue.
+// Fixed per model shape (independent of the batch), so a graph's result is bitwise the same
+// whatever batch it is part of.  GMC_LDS_SLICES_PER_WG overrides (tuning runs only).
 int gmc_lds_groups(const gmc_batch *b, int F) {
-    const Shape sh = pick_shape(b->n_max, b->nnz_max);
-    if (!sh.fs) return 0;
-    const int slices = (F + sh.fs - 1) / sh.fs;
-    // two slices per workgroup amortise the index load; fixed (independent of the batch) so a
-    // graph's result is bitwise the same whatever batch it is part of
-    return (slices + 1) / 2;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    if (!fs) return 0;
+    const int slices = (F + fs - 1) / fs;
+    static const int per_env = getenv("GMC_LDS_SLICES_PER_WG") ? atoi(getenv("GMC_LDS_SLICES_PER_WG")) : 0;
+    int per = per_env > 0 ? per_env : 4;
+    if (per > kMaxSlicesPerWg) per = kMaxSlicesPerWg;
+    return (slices + per - 1) / per;
 }
 
 // Y = act(scale * A_g @ X + bias) for every graph of the batch, LDS-staged; optional fused
@@ -360,47 +437,45 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int shared
     if (!b || !X || !Y) return GMC_ERR_NULL;
     if (F % 4 || ldx % 4 || ldy % 4 || !gmc_aligned16(X) || !gmc_aligned16(Y) || (bias && !gmc_aligned16(bias)))
         return GMC_ERR_ALIGN;
-    const Shape sh = pick_shape(b->n_max, b->nnz_max);
-    if (sh.fs == 0) return GMC_ERR_UNSUPPORTED;
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     if (b->B == 0) return GMC_OK;
-    TileArgs a{*b, X, ldx, shared_src, use_vals && b->vals != nullptr, scale, bias, relu, Y, ldy, F,
-               (F + sh.fs - 1) / sh.fs, gmc_lds_groups(b, F), W2, Zpart, 0};
-    static const int dbg = getenv("GMC_LDS_DBG") ? atoi(getenv("GMC_LDS_DBG")) : 0;
-    a.dbg = dbg;
-    const size_t lds = lds_bytes(b->n_max, b->nnz_max, sh.fs);
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    TileArgs a{*b, X, ldx, shared_src, use_vals && b->ell_vals != nullptr, scale, bias, relu, Y, ldy, F,
+               (F + fs - 1) / fs, gmc_lds_groups(b, F), W2, Zpart, 0};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(tag, st);
-    if (sh.threads == 512) {
-        switch (sh.fs) {
-            case 64: return launch_spmm<64, 512>(a, lds, st);
-            case 32: return launch_spmm<32, 512>(a, lds, st);
-            default: return launch_spmm<16, 512>(a, lds, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_spmm<64, 8>(a, lds, st);
+            case 32: return launch_spmm<32, 8>(a, lds, st);
+            default: return launch_spmm<16, 8>(a, lds, st);
         }
     }
-    switch (sh.fs) {
-        case 32: return launch_spmm<32, 1024>(a, lds, st);
-        case 16: return launch_spmm<16, 1024>(a, lds, st);
-        default: return launch_spmm<8, 1024>(a, lds, st);
+    switch (fs) {
+        case 64: return launch_spmm<64, 16>(a, lds, st);
+        case 32: return launch_spmm<32, 16>(a, lds, st);
+        default: return launch_spmm<16, 16>(a, lds, st);
     }
 }
 
-// dW1 partials: out[chunk][v][:] = sum_{g in chunk} sum_e vals[e] * U[g][lcol[e], :], v < n_max
+// dW1 partials: out[chunk][v][:] = sum_{g in chunk} sum_e vals[e] * U[g][nbr(e), :], v < n_max
 int gmc_dw1_lds_launch(const gmc_batch *b, const float *U, long ldu, float *out, int F, int chunks,
                        int graphs_per_chunk, hipStream_t st) {
-    const Shape sh = pick_shape(b->n_max, b->nnz_max);
-    if (sh.fs == 0) return GMC_ERR_UNSUPPORTED;
-    Dw1TileArgs a{*b, U, ldu, out, F, (F + sh.fs - 1) / sh.fs, chunks, graphs_per_chunk};
-    const size_t lds = lds_bytes(b->n_max, b->nnz_max, sh.fs);
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    Dw1TileArgs a{*b, U, ldu, out, F, (F + fs - 1) / fs, chunks, graphs_per_chunk};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(GMC_K_DW1, st);
-    if (sh.threads == 512) {
-        switch (sh.fs) {
-            case 64: return launch_dw1<64, 512>(a, lds, st);
-            case 32: return launch_dw1<32, 512>(a, lds, st);
-            default: return launch_dw1<16, 512>(a, lds, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_dw1<64, 8>(a, lds, st);
+            case 32: return launch_dw1<32, 8>(a, lds, st);
+            default: return launch_dw1<16, 8>(a, lds, st);
         }
     }
-    switch (sh.fs) {
-        case 32: return launch_dw1<32, 1024>(a, lds, st);
-        case 16: return launch_dw1<16, 1024>(a, lds, st);
-        default: return launch_dw1<8, 1024>(a, lds, st);
+    switch (fs) {
+        case 64: return launch_dw1<64, 16>(a, lds, st);
+        case 32: return launch_dw1<32, 16>(a, lds, st);
+        default: return launch_dw1<16, 16>(a, lds, st);
     }
 }

@@ -142,6 +142,10 @@ def from_networkx(nx_graph) -> GraphHandle:
                        None if bool(np.all(ww == 1.0)) else ww)
 
 
+def self_fits_u16(ns) -> bool:
+    return bool(ns.size) and int(ns.max()) < 65535
+
+
 class GraphBatch:
     """Block-diagonal batch resident on one GPU; mirrors ``struct gmc_batch``."""
 
@@ -175,8 +179,23 @@ class GraphBatch:
             gcol[eoff[g]:eoff[g + 1]] = h.col + goff[g]
             if vals is not None and values[g] is not None:
                 vals[eoff[g]:eoff[g + 1]] = values[g]
-        deg = np.diff(rowptr).astype(np.float32)
+        degi = np.diff(rowptr)
+        deg = degi.astype(np.float32)
         dinv = (1.0 / np.sqrt(np.maximum(deg, 1.0))).astype(np.float32)
+        # ELL copy for the LDS-tiled kernels: W slots per row, padded with the graph's node
+        # count (the id of the all-zero tile row) / weight 0
+        ell = ell_vals = None
+        max_deg = int(degi.max()) if degi.size else 0
+        W = 8 if max_deg <= 8 else 16
+        if 0 < max_deg <= 16 and self_fits_u16(ns):
+            R = int(goff[-1])
+            slot = np.arange(int(eoff[-1]), dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), degi)
+            rows = np.repeat(np.arange(R, dtype=np.int64), degi)
+            ell = np.repeat(ns.astype(np.uint16), ns)[:, None].repeat(W, axis=1)
+            ell[rows, slot] = lcol.astype(np.uint16)
+            if vals is not None:
+                ell_vals = np.zeros((R, W), np.float32)
+                ell_vals[rows, slot] = vals
 
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
@@ -188,11 +207,15 @@ class GraphBatch:
         self.rowptr, self.gcol, self.lcol = dev(rowptr), dev(gcol), dev(lcol)
         self.vals = None if vals is None else dev(vals)
         self.dinv = dev(dinv)
+        self.ell = None if ell is None else torch.from_numpy(ell.view(np.int16)).to(device)
+        self.ell_vals = None if ell_vals is None else dev(ell_vals)
         self.c = hip.GmcBatch(
             B=self.B, R=self.R, nnz=self.nnz, n_max=self.n_max, uniform_n=self.uniform_n,
             nnz_max=int(nnzs.max()) if B else 0,
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
-            lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv))
+            lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv),
+            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals),
+            ell_width=W if ell is not None else 0, reserved=0)
 
     def ref(self):
         return C.byref(self.c)

@@ -35,6 +35,7 @@ class GmcBatch(C.Structure):
         ("uniform_n", C.c_int32), ("nnz_max", C.c_int32),
         ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
         ("vals", C.c_void_p), ("dinv", C.c_void_p),
+        ("ell", C.c_void_p), ("ell_vals", C.c_void_p), ("ell_width", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -62,6 +62,13 @@ typedef struct gmc_batch {
     const int32_t *lcol;   /* [nnz] neighbour as local node id (row of W1 / column of X) */
     const float *vals;     /* [nnz] edge weight = X[u,v], or NULL when all ones */
     const float *dinv;     /* [R] clamp(degree,1)^-1/2  (in == out degree: undirected) */
+    /* Optional ELL copy of the same structure for the LDS-tiled kernels (NULL: row kernels
+     * only): W = ell_width slots per row (8 or 16, >= max degree), local neighbour ids in
+     * CSR order padded with n_g (the id of an all-zero row), weights padded with 0. */
+    const uint16_t *ell;   /* [R][W] */
+    const float *ell_vals; /* [R][W] or NULL when all ones */
+    int32_t ell_width;
+    int32_t reserved;
 } gmc_batch;
 
 /* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):
