@@ -6,6 +6,10 @@
 // launchers defined in the kernel files
 int gmc_head_bwd_launch(const gmc_batch *, const float *, const float *, float *, float *, hipStream_t);
 int gmc_hidden_tiles(int R);
+int gmc_hidden_slab_tiles(int R);
+int gmc_hidden_bwd_slab_launch(const float *, const float *, const float *, const float *, float *, float *, int,
+                               int, int, hipStream_t);
+int gmc_lds_slice_width(const gmc_batch *b);
 int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
                           long, float *, int, int, hipStream_t);
 int gmc_colsum_reduce_launch(const float *, int, int, float *, float *, const float *, int, float *,
@@ -14,14 +18,14 @@ size_t gmc_dw1_scratch_floats(const gmc_batch *b, int N, int F, bool lds);
 int gmc_dw1_launch(const gmc_batch *, const float *, long, float *, float *, int, int, bool, hipStream_t);
 bool gmc_lds_fits(const gmc_batch *b);
 int gmc_lds_groups(const gmc_batch *b, int F);
-int gmc_spmm_lds_launch(const gmc_batch *, const float *, long, int, int, const float *, const float *, int,
-                        float *, long, int, const float *, float *, int, hipStream_t);
+int gmc_spmm_lds_launch(const gmc_batch *, const float *, long, int, int, int, const float *, const float *, int,
+                        float *, long, int, int, const float *, float *, int, hipStream_t);
 
 namespace {
 
 struct Workspace {
-    long ld;         // leading dimension of the [R,F] buffers: F rounded up to 32 floats so every
-                     // row (and every 128 B column slice of it) starts on a 128 B boundary
+    long ld;         // row kernels: leading dimension of the [R,F] buffers (F rounded up to 32 floats)
+    int fs;          // LDS kernels: slice width of the slab layout [slice][R][fs] (0 = row-major)
     int zparts;      // partials in Z0 (LDS path: one per slice group)
     float *T0;       // [R,ld]  (X o dinv)@W1, later Gs = dinv o Gpre
     float *H;        // [R,ld]  relu(conv1), later U = dinv o (A @ Gs)
@@ -56,13 +60,15 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     };
     const size_t R = (size_t)b->R, F = (size_t)m->F;
     w.ld = (long)((F + 31) / 32 * 32);
-    w.zparts = use_lds(b) ? gmc_lds_groups(b, m->F) : 1;
-    w.T0 = take(R * w.ld);
-    w.H = take(R * w.ld);
+    w.fs = use_lds(b) ? gmc_lds_slice_width(b) : 0;
+    w.zparts = w.fs ? gmc_lds_groups(b, m->F) : 1;
+    const size_t cols = w.fs ? (F + w.fs - 1) / w.fs * w.fs : (size_t)w.ld;
+    w.T0 = take(R * cols);
+    w.H = take(R * cols);
     w.Z0 = take((size_t)w.zparts * R * 3);
     if (training) {
         w.GY2 = take(R * 3);
-        w.part = take((size_t)gmc_hidden_tiles(b->R) * F * 4);
+        w.part = take((size_t)(w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R)) * F * 4);
         w.db2part = take((size_t)b->B * 3);
         w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
     }
@@ -87,25 +93,24 @@ int group_rows(const gmc_batch *b) { return b->uniform_n > 0 ? b->uniform_n : b-
 
 // Y = act(dinv o (A @ X) + bias) over the batch with either implementation; Z0 (optional) gets
 // the fused layer-2 feature transform (zparts partials on the LDS path).
-int aggregate(const gmc_batch *b, const float *X, float *Y, long ld, int F, const float *bias, int relu,
+int aggregate(const gmc_batch *b, const Workspace &w, const float *X, float *Y, int F, const float *bias, int relu,
               const float *W2, float *Z0, int tag, hipStream_t st) {
-    if (use_lds(b))
-        return gmc_spmm_lds_launch(b, X, ld, 0, 0, b->dinv, bias, relu, Y, ld, F, W2, Z0, tag, st);
-    return gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, X, ld, bias, relu, Y, ld, b->R, F,
+    if (w.fs)
+        return gmc_spmm_lds_launch(b, X, w.ld, 1, 0, 0, b->dinv, bias, relu, Y, w.ld, 1, F, W2, Z0, tag, st);
+    return gmc_spmm_launch(b->rowptr, b->gcol, nullptr, b->dinv, X, w.ld, bias, relu, Y, w.ld, b->R, F,
                            group_rows(b), W2, Z0, tag, st);
 }
 
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
     const int F = m->F;
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
-    int rc = use_lds(b)
-                 ? gmc_spmm_lds_launch(b, m->W1, F, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, F, nullptr, nullptr,
-                                       GMC_K_GATHER_W1, st)
-                 : gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, w.ld,
-                                   b->R, F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
+    int rc = w.fs ? gmc_spmm_lds_launch(b, m->W1, F, 0, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, 1, F, nullptr,
+                                        nullptr, GMC_K_GATHER_W1, st)
+                  : gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, w.ld,
+                                    b->R, F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
     if (rc) return rc;
     // layer 1 aggregation + bias + relu with the layer 2 feature transform fused in
-    return aggregate(b, w.T0, w.H, w.ld, F, m->b1, 1, m->W2, w.Z0, GMC_K_AGG_FWD, st);
+    return aggregate(b, w, w.T0, w.H, F, m->b1, 1, m->W2, w.Z0, GMC_K_AGG_FWD, st);
 }
 
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
@@ -113,15 +118,16 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
-    int rc = gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
+    int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, m->W2, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
+                  : gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
     if (rc) return rc;
-    rc = gmc_colsum_reduce_launch(w.part, gmc_hidden_tiles(b->R), m->F, dW2, db1, w.db2part, b->B,
-                                  db2, st);
+    rc = gmc_colsum_reduce_launch(w.part, w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R), m->F,
+                                  dW2, db1, w.db2part, b->B, db2, st);
     if (rc) return rc;
     // conv1 backward aggregation:  U = dinv o (A @ Gs)
-    rc = aggregate(b, Gs, U, w.ld, m->F, nullptr, 0, nullptr, nullptr, GMC_K_AGG_BWD, st);
+    rc = aggregate(b, w, Gs, U, m->F, nullptr, 0, nullptr, nullptr, GMC_K_AGG_BWD, st);
     if (rc) return rc;
-    return gmc_dw1_launch(b, U, w.ld, dW1, w.dw1part, m->N, m->F, use_lds(b), st);
+    return gmc_dw1_launch(b, U, w.ld, dW1, w.dw1part, m->N, m->F, w.fs != 0, st);
 }
 
 }  // namespace

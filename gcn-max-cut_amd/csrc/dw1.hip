@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, fl
 }  // namespace
 
 bool gmc_lds_fits(const gmc_batch *b);
-int gmc_dw1_lds_launch(const gmc_batch *, const float *, long, float *, int, int, int, hipStream_t);
+int gmc_dw1_lds_launch(const gmc_batch *, const float *, long, int, float *, int, int, int, hipStream_t);
 
 // chunks the batch is split into for parallelism
 int gmc_dw1_chunks(int B, bool lds) {
@@ -132,7 +132,7 @@ int gmc_dw1_launch(const gmc_batch *b, const float *U, long ldu, float *dW1, flo
     const int per = (b->B + chunks - 1) / chunks;
     int rows = N;
     if (lds) {
-        int rc = gmc_dw1_lds_launch(b, U, ldu, scratch, F, chunks, per, st);
+        int rc = gmc_dw1_lds_launch(b, U, ldu, 1, scratch, F, chunks, per, st);
         if (rc) return rc;
         rows = b->n_max;
     } else {

@@ -83,6 +83,85 @@ __global__ __launch_bounds__(kColThreads * kRowLanes) void hidden_bwd_kernel(Hid
     }
 }
 
+// Same pass over the slab layout [slice][R][FS] the LDS-tiled kernels use: a block owns
+// (row tile, slice); thread (row lane, q) streams FS-wide rows contiguously (a 256-thread pass
+// covers 256/Q full slab rows = 4 KiB contiguous), keeps the partials of its 4 columns in
+// registers, then the lanes/waves sharing a q are folded in a fixed order.
+constexpr int kSlabTileRows = 256;
+
+struct HiddenSlabArgs {
+    const float *H;
+    const float *GY2;
+    const float *W2;
+    const float *dinv;
+    float *Gs;
+    float *part;  // [tiles][F][4]
+    int R;
+    int F;
+};
+
+template <int FS>
+__global__ __launch_bounds__(256) void hidden_bwd_slab_kernel(HiddenSlabArgs a) {
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = 256 / Q;
+    __shared__ float red[4][Q][16];
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int s = blockIdx.y;
+    const int f0 = s * FS + 4 * q;
+    const bool on = f0 < a.F;
+    float w[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w[j][k] = on ? a.W2[(long)(f0 + j) * 3 + k] : 0.f;
+    float acc[16] = {};  // [j][0..2] dW2, [j][3] db1
+    const long slab = (long)s * a.R * FS;
+    const int rbeg = blockIdx.x * kSlabTileRows;
+    const int rend = min(rbeg + kSlabTileRows, a.R);
+#pragma unroll 4
+    for (int r = rbeg + rl; r < rend; r += kRowsPerPass) {
+        const long off = slab + (long)r * FS + 4 * q;
+        const float4 h = *reinterpret_cast<const float4 *>(a.H + off);
+        const float d = a.dinv[r];
+        const float g0 = a.GY2[(long)r * 3], g1 = a.GY2[(long)r * 3 + 1], g2 = a.GY2[(long)r * 3 + 2];
+        const float hv[4] = {h.x, h.y, h.z, h.w};
+        float gs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gh = g0 * w[j][0] + g1 * w[j][1] + g2 * w[j][2];
+            const float gpre = (on && hv[j] > 0.f) ? gh * d : 0.f;
+            gs[j] = gpre * d;
+            const float hd = on ? hv[j] * d : 0.f;
+            acc[4 * j + 0] = fmaf(hd, g0, acc[4 * j + 0]);
+            acc[4 * j + 1] = fmaf(hd, g1, acc[4 * j + 1]);
+            acc[4 * j + 2] = fmaf(hd, g2, acc[4 * j + 2]);
+            acc[4 * j + 3] += gpre;
+        }
+        *reinterpret_cast<float4 *>(a.Gs + off) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    // fold lanes with equal q inside the wave (xor over the lane bits above log2 Q), then waves
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 32; o >= Q; o >>= 1) acc[i] += __shfl_xor(acc[i], o, GMC_WAVE);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < Q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][lane][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q * 4 && s * FS + 4 * (threadIdx.x / 4) < a.F) {  // thread = (q, j)
+        const int qq = threadIdx.x / 4, j = threadIdx.x % 4;
+        float4 o;
+        float *op = reinterpret_cast<float *>(&o);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            op[c] = ((red[0][qq][4 * j + c] + red[1][qq][4 * j + c]) + red[2][qq][4 * j + c]) + red[3][qq][4 * j + c];
+        reinterpret_cast<float4 *>(a.part)[(long)blockIdx.x * a.F + s * FS + 4 * qq + j] = o;
+    }
+}
+
 // dW2[f,k], db1[f] = sum over tiles (ascending) of part[tile][f][:]; db2 = sum over graphs.
 struct ReduceArgs {
     const float *part;
@@ -140,6 +219,26 @@ int gmc_hidden_bwd_launch(const float *H, long ldh, const float *GY2, const floa
     dim3 grid(gmc_hidden_tiles(R), (F / 4 + kColThreads - 1) / kColThreads);
     GmcProbeScope probe(GMC_K_HIDDEN_BWD, st);
     hipLaunchKernelGGL(hidden_bwd_kernel, grid, dim3(kColThreads * kRowLanes), 0, st, a);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
+int gmc_hidden_slab_tiles(int R) { return (R + kSlabTileRows - 1) / kSlabTileRows; }
+
+// slab-layout form: H, Gs are [slice][R][fs]; part must hold gmc_hidden_slab_tiles(R)*F*4 floats
+int gmc_hidden_bwd_slab_launch(const float *H, const float *GY2, const float *W2, const float *dinv,
+                               float *Gs, float *part, int R, int F, int fs, hipStream_t st) {
+    if (F % 4) return GMC_ERR_ALIGN;
+    if (R == 0) return GMC_OK;
+    HiddenSlabArgs a{H, GY2, W2, dinv, Gs, part, R, F};
+    dim3 grid(gmc_hidden_slab_tiles(R), (F + fs - 1) / fs);
+    GmcProbeScope probe(GMC_K_HIDDEN_BWD, st);
+    switch (fs) {
+        case 64: hipLaunchKernelGGL(hidden_bwd_slab_kernel<64>, grid, dim3(256), 0, st, a); break;
+        case 32: hipLaunchKernelGGL(hidden_bwd_slab_kernel<32>, grid, dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL(hidden_bwd_slab_kernel<16>, grid, dim3(256), 0, st, a); break;
+        default: return GMC_ERR_UNSUPPORTED;
+    }
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }

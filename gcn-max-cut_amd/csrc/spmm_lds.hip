@@ -39,14 +39,15 @@ constexpr int kThreads = 1024;
 struct TileArgs {
     gmc_batch b;
     const float *X;     // source rows: batch rows (shared_src = 0) or one shared table (W1)
-    long ldx;
+    long x_rs, x_ss;    // element (row, col) of X lives at row*x_rs + (col/FS)*x_ss + col%FS:
+                        // row-major = (ld, FS); slab layout [slice][row][FS] = (FS, R*FS)
     int shared_src;
     int use_vals;
     const float *scale;
     const float *bias;
     int relu;
     float *Y;
-    long ldy;
+    long y_rs, y_ss;
     int F;
     int slices;          // ceil(F / FS)
     int groups;          // slice groups per graph (workgroups per graph)
@@ -171,10 +172,10 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     float *cw2 = cbias + per * FS;                                          // [per*FS][3] W2 rows of my columns
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
-    const float *src0 = a.X + (a.shared_src ? 0L : (long)r0 * a.ldx) + 4 * q;
+    const float *src0 = a.X + (a.shared_src ? 0L : (long)r0 * a.x_rs) + 4 * q;
 
     float4 pf[ACC];
-    prefetch_tile<FS, ACC>(src0 + s_beg * FS, a.ldx, n, s_beg * FS + 4 * q < a.F, lrow, pf);
+    prefetch_tile<FS, ACC>(src0 + s_beg * a.x_ss, a.x_rs, n, s_beg * FS + 4 * q < a.F, lrow, pf);
 
     float zr[EPI ? ACC : 1][3] = {};
     float sc[ACC];
@@ -229,12 +230,13 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            if (l < n && c < a.F && !(GMC_DBG & 4)) *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.ldy + c) = y[k];
+            if (l < n && c < a.F && !(GMC_DBG & 4))
+                *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)s * a.y_ss + 4 * q) = y[k];
         }
     };
     auto prefetch = [&](int s) {  // clamped: past the last slice re-read it (L2 hit, never used)
-        const int c = min(s, s_end - 1) * FS;
-        prefetch_tile<FS, ACC>(src0 + c, a.ldx, n, c + 4 * q < a.F, lrow, pf);
+        const int sc_ = min(s, s_end - 1);
+        prefetch_tile<FS, ACC>(src0 + sc_ * a.x_ss, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, pf);
     };
 
     // peeled first slice, then a branch-free steady state
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
 struct Dw1TileArgs {
     gmc_batch b;
     const float *U;
-    long ldu;
+    long u_rs, u_ss;  // layout of U (see TileArgs)
     float *out;   // [chunks][n_max][F]
     int F;
     int slices;
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
     auto fetch = [&](int g) {  // tile slice + neighbour table of graph g -> registers
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
-        prefetch_tile<FS, ACC>(a.U + (long)r0 * a.ldu + c0 + 4 * q, a.ldu, n, col_on, lrow, pf);
+        prefetch_tile<FS, ACC>(a.U + (long)r0 * a.u_rs + (long)s * a.u_ss + 4 * q, a.u_rs, n, col_on, lrow, pf);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
@@ -408,6 +410,9 @@ int launch_dw1(const Dw1TileArgs &a, size_t lds, hipStream_t st) {
 
 }  // namespace
 
+// slice width the LDS kernels (and the slab layout) use for this batch; 0 = row kernels
+int gmc_lds_slice_width(const gmc_batch *b) { return b->ell ? pick_fs(b->n_max, b->ell_width) : 0; }
+
 bool gmc_lds_fits(const gmc_batch *b) {
     if (!b->ell) return false;
     const int fs = pick_fs(b->n_max, b->ell_width);
@@ -431,16 +436,20 @@ int gmc_lds_groups(const gmc_batch *b, int F) {
 
 // Y = act(scale * A_g @ X + bias) for every graph of the batch, LDS-staged; optional fused
 // Zpart[group][r][:] = scale[r] * (Y[r, group's columns] @ W2[group's rows]).
-int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int shared_src, int use_vals,
-                        const float *scale, const float *bias, int relu, float *Y, long ldy, int F,
+// x_slab / y_slab: the operand uses the slab layout [slice][R][FS] (ld ignored) instead of
+// row-major with leading dimension ld.
+int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int x_slab, int shared_src, int use_vals,
+                        const float *scale, const float *bias, int relu, float *Y, long ldy, int y_slab, int F,
                         const float *W2, float *Zpart, int tag, hipStream_t st) {
     if (!b || !X || !Y) return GMC_ERR_NULL;
-    if (F % 4 || ldx % 4 || ldy % 4 || !gmc_aligned16(X) || !gmc_aligned16(Y) || (bias && !gmc_aligned16(bias)))
+    if (F % 4 || ldx % 4 || ldy % 4 || !gmc_aligned16(X) || !gmc_aligned16(Y))
         return GMC_ERR_ALIGN;
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
-    TileArgs a{*b, X, ldx, shared_src, use_vals && b->ell_vals != nullptr, scale, bias, relu, Y, ldy, F,
+    const long slab_ss = (long)b->R * fs;
+    TileArgs a{*b, X, x_slab ? fs : ldx, x_slab ? slab_ss : fs, shared_src, use_vals && b->ell_vals != nullptr,
+               scale, bias, relu, Y, y_slab ? fs : ldy, y_slab ? slab_ss : fs, F,
                (F + fs - 1) / fs, gmc_lds_groups(b, F), W2, Zpart, 0};
     const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(tag, st);
@@ -459,11 +468,12 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int shared
 }
 
 // dW1 partials: out[chunk][v][:] = sum_{g in chunk} sum_e vals[e] * U[g][nbr(e), :], v < n_max
-int gmc_dw1_lds_launch(const gmc_batch *b, const float *U, long ldu, float *out, int F, int chunks,
+int gmc_dw1_lds_launch(const gmc_batch *b, const float *U, long ldu, int u_slab, float *out, int F, int chunks,
                        int graphs_per_chunk, hipStream_t st) {
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     const int fs = pick_fs(b->n_max, b->ell_width);
-    Dw1TileArgs a{*b, U, ldu, out, F, (F + fs - 1) / fs, chunks, graphs_per_chunk};
+    Dw1TileArgs a{*b, U, u_slab ? fs : ldu, u_slab ? (long)b->R * fs : fs, out, F, (F + fs - 1) / fs, chunks,
+                  graphs_per_chunk};
     const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(GMC_K_DW1, st);
     if (b->ell_width == 8) {
