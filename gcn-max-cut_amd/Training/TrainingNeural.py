@@ -276,9 +276,9 @@ class FusedTrainer:
     (so ``optimizer.state_dict()`` has the reference's layout)."""
 
     def __init__(self, net: GCNSoftmax, optimizer, config: TrainingConfig, graphs_per_step: int = 1,
-                 local_shard: bool = False):
+                 local_shard: bool = False, engine=None):
         self.net, self.optimizer, self.config = net, optimizer, config
-        self.eng = net.engine()
+        self.eng = engine if engine is not None else net.engine()
         self.graphs_per_step = graphs_per_step
         # local_shard: `dataset` already is this rank's shard (graphs_per_step of ITS graphs per
         # step); otherwise every rank holds the whole dataset and takes its slice of each group
@@ -303,7 +303,7 @@ class FusedTrainer:
             mine = group if self.local_shard else [group[i] for i in shard_for_rank(len(group), self.rank, self.world)]
             handles = [it[0] for it in mine]
             vals = [h.edge_values(it[1]) for h, it in zip(handles, mine)]
-            self._batches.append(GraphBatch(handles, vals, dev))
+            self._batches.append(self.eng.make_batch(handles, vals))
         rmax = max((b.R for b in self._batches), default=0)
         bmax = max((b.B for b in self._batches), default=0)
         self._out = (torch.empty((rmax, 3), dtype=torch.float32, device=dev),

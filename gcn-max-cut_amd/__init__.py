@@ -9,7 +9,18 @@ directory on ``sys.path`` to get the reference's own import roots
 (``Training.TrainingNeural``, ``DataGenerator.graphExtender``, ``commons``, ``python.*``).
 """
 from . import hip  # noqa: F401
-from .graph import DGLError, GraphBatch, GraphHandle, from_networkx  # noqa: F401
+from .graph import BatchArrays, DGLError, GraphBatch, GraphHandle, from_networkx  # noqa: F401
 from .engine import FusedEngine, shard_for_rank  # noqa: F401
 
 __version__ = "0.1.0"
+
+
+def install_compat() -> str:
+    """Put the reference's import roots (``Training.TrainingNeural``, ``DataGenerator.graphExtender``,
+    ``commons``, ``python.*``) on ``sys.path`` so unmodified notebook imports resolve here."""
+    import os
+    import sys
+    path = os.path.join(__path__[0], "compat")
+    if path not in sys.path:
+        sys.path.insert(0, path)
+    return path

@@ -45,17 +45,17 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
 }  // namespace
 
 extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count,
-                            float lr, float beta1, float beta2, float eps, int32_t step,
+                            double lr, double beta1, double beta2, double eps, int32_t step,
                             gmc_stream_t stream) {
     if (!param || !grad || !m || !v) return GMC_ERR_NULL;
     if (count < 0 || step < 1) return GMC_ERR_SHAPE;
     if (!gmc_aligned16(param) || !gmc_aligned16(grad) || !gmc_aligned16(m) || !gmc_aligned16(v))
         return GMC_ERR_ALIGN;
     if (count == 0) return GMC_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    AdamArgs a{param, grad, m, v, (long)count, 1.0f - beta1, beta2, 1.0f - beta2,
-               (float)((double)lr / bc1), (float)sqrt(bc2), eps};
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a{param, grad, m, v, (long)count, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+               (float)(lr / bc1), (float)sqrt(bc2), (float)eps};
     long blocks = ((count >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;

@@ -78,6 +78,9 @@ class FusedEngine:
         views = self.views()
         return all(named[k].data_ptr() == views[k].data_ptr() for k in PARAM_ORDER)
 
+    def make_batch(self, handles, values=None) -> GraphBatch:
+        return GraphBatch(handles, values, self.device)
+
     # ---- scratch
     def _workspace(self, batch: GraphBatch, training: bool) -> Tuple[torch.Tensor, int]:
         need = int(self.lib.gmc_workspace_bytes(batch.ref(), C.byref(self._model), int(training)))

@@ -142,17 +142,11 @@ def from_networkx(nx_graph) -> GraphHandle:
                        None if bool(np.all(ww == 1.0)) else ww)
 
 
-def self_fits_u16(ns) -> bool:
-    return bool(ns.size) and int(ns.max()) < 65535
+class BatchArrays:
+    """Host-side (numpy) form of a block-diagonal batch: everything ``struct gmc_batch``
+    points to, built without touching a GPU (so the layout is testable on CPU)."""
 
-
-class GraphBatch:
-    """Block-diagonal batch resident on one GPU; mirrors ``struct gmc_batch``."""
-
-    def __init__(self, handles: Sequence[GraphHandle], values: Optional[Sequence[Optional[np.ndarray]]] = None,
-                 device: Optional[torch.device] = None):
-        device = device or hip.require_gpu()
-        self.device = device
+    def __init__(self, handles: Sequence[GraphHandle], values: Optional[Sequence[Optional[np.ndarray]]] = None):
         B = len(handles)
         ns = np.asarray([h.n for h in handles], np.int64)
         for h in handles:
@@ -180,14 +174,13 @@ class GraphBatch:
             if vals is not None and values[g] is not None:
                 vals[eoff[g]:eoff[g + 1]] = values[g]
         degi = np.diff(rowptr)
-        deg = degi.astype(np.float32)
-        dinv = (1.0 / np.sqrt(np.maximum(deg, 1.0))).astype(np.float32)
-        # ELL copy for the LDS-tiled kernels: W slots per row, padded with the graph's node
-        # count (the id of the all-zero tile row) / weight 0
+        dinv = (1.0 / np.sqrt(np.maximum(degi.astype(np.float32), 1.0))).astype(np.float32)
+        # ELL copy for the LDS-tiled kernels: W slots per row (8 or 16), neighbours in CSR order,
+        # padded with the graph's node count (the id of the all-zero tile row) / weight 0
         ell = ell_vals = None
         max_deg = int(degi.max()) if degi.size else 0
         W = 8 if max_deg <= 8 else 16
-        if 0 < max_deg <= 16 and self_fits_u16(ns):
+        if 0 < max_deg <= 16 and int(ns.max()) < 65535:
             R = int(goff[-1])
             slot = np.arange(int(eoff[-1]), dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), degi)
             rows = np.repeat(np.arange(R, dtype=np.int64), degi)
@@ -196,26 +189,37 @@ class GraphBatch:
             if vals is not None:
                 ell_vals = np.zeros((R, W), np.float32)
                 ell_vals[rows, slot] = vals
-
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
+        self.nnz_max = int(nnzs.max()) if B else 0
         self.uniform_n = int(ns[0]) if B and bool(np.all(ns == ns[0])) else 0
-        self.sizes = ns
-        self.goff_host = goff
-        dev = lambda a: torch.from_numpy(a).to(device)
-        self.goff = dev(goff.astype(np.int32))
-        self.rowptr, self.gcol, self.lcol = dev(rowptr), dev(gcol), dev(lcol)
-        self.vals = None if vals is None else dev(vals)
-        self.dinv = dev(dinv)
-        self.ell = None if ell is None else torch.from_numpy(ell.view(np.int16)).to(device)
-        self.ell_vals = None if ell_vals is None else dev(ell_vals)
+        self.sizes, self.goff = ns, goff
+        self.rowptr, self.gcol, self.lcol, self.vals, self.dinv = rowptr, gcol, lcol, vals, dinv
+        self.ell, self.ell_vals, self.ell_width = ell, ell_vals, (W if ell is not None else 0)
+
+
+class GraphBatch:
+    """Block-diagonal batch resident on one GPU; mirrors ``struct gmc_batch``."""
+
+    def __init__(self, handles: Sequence[GraphHandle], values: Optional[Sequence[Optional[np.ndarray]]] = None,
+                 device: Optional[torch.device] = None):
+        device = device or hip.require_gpu()
+        self.device = device
+        h = BatchArrays(handles, values)
+        self.host = h
+        self.B, self.R, self.nnz, self.n_max, self.uniform_n = h.B, h.R, h.nnz, h.n_max, h.uniform_n
+        self.sizes, self.goff_host = h.sizes, h.goff
+        dev = lambda a: None if a is None else torch.from_numpy(a).to(device)
+        self.goff = dev(h.goff.astype(np.int32))
+        self.rowptr, self.gcol, self.lcol = dev(h.rowptr), dev(h.gcol), dev(h.lcol)
+        self.vals, self.dinv = dev(h.vals), dev(h.dinv)
+        self.ell = None if h.ell is None else torch.from_numpy(h.ell.view(np.int16)).to(device)
+        self.ell_vals = dev(h.ell_vals)
         self.c = hip.GmcBatch(
-            B=self.B, R=self.R, nnz=self.nnz, n_max=self.n_max, uniform_n=self.uniform_n,
-            nnz_max=int(nnzs.max()) if B else 0,
+            B=h.B, R=h.R, nnz=h.nnz, n_max=h.n_max, uniform_n=h.uniform_n, nnz_max=h.nnz_max,
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
             lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv),
-            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals),
-            ell_width=W if ell is not None else 0, reserved=0)
+            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, reserved=0)
 
     def ref(self):
         return C.byref(self.c)

@@ -57,7 +57,7 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_spmm_f32.argtypes = [vp, vp, vp, vp, vp, i64, vp, C.c_int, vp, i64, i32, i32, i32, vp, vp, vp]
     lib.gmc_dense_hw2_f32.argtypes = [vp, i64, vp, vp, vp, i32, i32, vp]
     lib.gmc_head_f32.argtypes = [C.POINTER(GmcBatch), vp, i32, vp, f32, vp, vp, vp, vp, vp, vp]
-    lib.gmc_adam_f32.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    lib.gmc_adam_f32.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, i32, vp]
     lib.gmc_workspace_bytes.restype = sz
     lib.gmc_workspace_bytes.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), C.c_int]
     lib.gmc_forward.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), f32, vp, sz, vp, vp, vp, vp]

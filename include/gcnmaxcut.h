@@ -135,9 +135,11 @@ int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const
                  float *P, int32_t *S, float *loss, float *GY2, float *db2part, gmc_stream_t stream);
 
 /* torch.optim.Adam.step (TrainingNeural.py:337,:386) over one flat buffer, fused:
- * m,v update + bias correction + parameter update in a single sweep. step >= 1. */
-int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count, float lr,
-                 float beta1, float beta2, float eps, int32_t step, gmc_stream_t stream);
+ * m,v update + bias correction + parameter update in a single sweep. step >= 1.  The
+ * hyper-parameters are doubles because torch derives 1-beta, lr/bias_correction1 and
+ * sqrt(bias_correction2) in Python floats (doubles) before rounding them to fp32. */
+int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count, double lr,
+                 double beta1, double beta2, double eps, int32_t step, gmc_stream_t stream);
 
 /* ---- fused entry points ------------------------------------------------------------ */
 

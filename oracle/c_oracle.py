@@ -102,8 +102,8 @@ def backward(rowptr, col, val, N, W2, H, P, GP):
 
 
 def adam(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
-    lib().orc_adam(_opt(p), _opt(g), _opt(m), _opt(v), C.c_long(p.size), C.c_float(lr),
-                   C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_int(step))
+    lib().orc_adam(_opt(p), _opt(g), _opt(m), _opt(v), C.c_long(p.size), C.c_double(lr),
+                   C.c_double(beta1), C.c_double(beta2), C.c_double(eps), C.c_int(step))
 
 
 class CTrainer:
@@ -133,7 +133,7 @@ class CTrainer:
         self.t += 1
         rc = lib().orc_train_step(C.c_int(B), _opt(n_of), rp, cl, vl, C.c_int(self.N),
                                   C.c_int(self.F), C.c_int(self.K), _opt(self.flat),
-                                  _opt(self.grad), _opt(self.m), _opt(self.v), C.c_float(self.lr),
+                                  _opt(self.grad), _opt(self.m), _opt(self.v), C.c_double(self.lr),
                                   C.c_float(self.C), C.c_int(self.t), _opt(losses))
         if rc:
             raise RuntimeError(f"orc_train_step rc={rc}")

@@ -199,15 +199,16 @@ int orc_backward(int n, const int *rowptr, const int *col, const float *val, int
 
 /* torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay, no amsgrad),
  * single-tensor formulation: lerp, addcmul, sqrt/bc2_sqrt + eps, addcdiv. */
-int orc_adam(float *p, const float *g, float *m, float *v, long count, float lr,
-             float beta1, float beta2, float eps, int step) {
-    double bc1 = 1.0 - pow((double)beta1, (double)step);
-    double bc2 = 1.0 - pow((double)beta2, (double)step);
-    float step_size = (float)((double)lr / bc1);
+int orc_adam(float *p, const float *g, float *m, float *v, long count, double lr,
+             double beta1, double beta2, double eps_d, int step) {
+    double bc1 = 1.0 - pow(beta1, (double)step);
+    double bc2 = 1.0 - pow(beta2, (double)step);
+    float step_size = (float)(lr / bc1);
     float bc2_sqrt = (float)sqrt(bc2);
+    float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2), eps = (float)eps_d;
     for (long i = 0; i < count; ++i) {
-        m[i] = m[i] + (g[i] - m[i]) * (1.0f - beta1);
-        v[i] = v[i] * beta2 + (1.0f - beta2) * g[i] * g[i];
+        m[i] = m[i] + (g[i] - m[i]) * w1;
+        v[i] = v[i] * b2 + w2 * g[i] * g[i];
         float denom = sqrtf(v[i]) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (m[i] / denom);
     }
@@ -218,7 +219,7 @@ int orc_adam(float *p, const float *g, float *m, float *v, long count, float lr,
  * :371-386).  Parameters are one flat buffer [W1 | b1 | W2 | b2]; N = in_feats. */
 int orc_train_step(int B, const int *n_of, const int *const *rowptrs, const int *const *cols,
                    const float *const *vals, int N, int F, int K, float *params, float *grads,
-                   float *m, float *v, float lr, float C, int step, float *losses) {
+                   float *m, float *v, double lr, float C, int step, float *losses) {
     long oW1 = 0, ob1 = (long)N * F, oW2 = ob1 + F, ob2 = oW2 + (long)F * K, P_ = ob2 + K;
     memset(grads, 0, sizeof(float) * (size_t)P_);
     for (int b = 0; b < B; ++b) {
@@ -239,5 +240,5 @@ int orc_train_step(int B, const int *n_of, const int *const *rowptrs, const int 
         free(T0); free(H); free(Z0); free(Pm); free(GP); free(S);
         if (rc) return rc;
     }
-    return orc_adam(params, grads, m, v, P_, lr, 0.9f, 0.999f, 1e-8f, step);
+    return orc_adam(params, grads, m, v, P_, (double)lr, 0.9, 0.999, 1e-8, step);
 }

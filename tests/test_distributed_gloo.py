@@ -1,0 +1,127 @@
+"""N > 1 path on CPU: two gloo ranks drive the product's FusedTrainer (sharding, one
+all-reduce of the flat gradient per step, replicated Adam) with the oracle standing in for
+the HIP engine, and must reproduce the single-process batched step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPECS = [(40, 5, 1), (36, 6, 2), (30, 4, 3), (44, 7, 4), (32, 5, 5), (38, 6, 6)]
+HIDDEN = 8
+
+
+class OracleEngine:
+    """CPU stand-in with the FusedEngine surface the trainer uses (test-only)."""
+
+    def __init__(self, params):
+        from oracle import c_oracle as CO
+        self.CO = CO
+        self.device = torch.device("cpu")
+        self.N, self.F = params["conv1.weight"].shape
+        self.flat = np.concatenate([params[k].ravel() for k in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")]).astype(np.float32)
+        self.count = self.flat.size
+        self.grad = torch.zeros(self.count + 4)
+        self.m, self.v = np.zeros_like(self.flat), np.zeros_like(self.flat)
+        self.step_count = 0
+
+    def unpack(self):
+        N, F = self.N, self.F
+        o = np.cumsum([0, N * F, F, F * 3, 3])
+        f = self.flat
+        return f[o[0]:o[1]].reshape(N, F), f[o[1]:o[2]], f[o[2]:o[3]].reshape(F, 3), f[o[3]:o[4]]
+
+    def make_batch(self, handles, values=None):
+        class B:
+            pass
+        b = B()
+        b.B, b.R = len(handles), sum(h.n for h in handles)
+        b.csrs = [(h.rowptr, h.col, None) for h in handles]
+        return b
+
+    def train_fwd_bwd(self, batch, C_=1.0, out=None):
+        CO = self.CO
+        W1, b1, W2, b2 = self.unpack()
+        g = [np.zeros_like(W1), np.zeros_like(b1), np.zeros_like(W2), np.zeros_like(b2)]
+        for i, (rp, cl, vl) in enumerate(batch.csrs):
+            f = CO.forward(rp, cl, vl, W1, b1, W2, b2)
+            S, loss, GP = CO.loss_grad(rp, cl, vl, f["P"], C_)
+            for a, d in zip(g, CO.backward(rp, cl, vl, self.N, W2, f["H"], f["P"], GP)):
+                a += d
+            out[2][i] = loss
+        self.grad[:self.count] = torch.from_numpy(np.concatenate([x.ravel() for x in g]))
+
+    def allreduce_grad(self):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
+
+    def adam_step(self, lr):
+        self.step_count += 1
+        self.CO.adam(self.flat, self.grad[:self.count].numpy().copy(), self.m, self.v, lr, self.step_count)
+
+
+def run_epochs(rank, world, port, graphs_per_step, queue):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    from oracle import ref_dense as R
+    from tests import util
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        ds = util.product_dataset(SPECS)
+    cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=HIDDEN)
+    net, embed, opt = T.setup_model_and_optimizer(cfg)
+    params = {k: v.numpy() for k, v in R.init_params(1000, HIDDEN, 3, seed=4).items()}
+    eng = OracleEngine(params)
+    tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=graphs_per_step, engine=eng)
+    assert tr.world == world and tr.rank == rank
+    losses, grads = [], None
+    for epoch in range(2):
+        losses.append(tr.epoch(ds))
+        if epoch == 0:
+            grads = eng.grad[:eng.count].numpy().copy()
+    sizes = [b.B for b in tr._batches]
+    queue.put((rank, losses, eng.flat.copy(), grads, sizes))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(world, graphs_per_step):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=run_epochs, args=(r, world, port, graphs_per_step, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return out
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_reproduce_the_single_process_batched_step(built):
+    (_, loss1, flat1, grad1, sizes1), = launch(1, 6)
+    r0, r1 = launch(2, 3)                       # 2 ranks x 3 graphs per rank per step == one 6-graph step
+    assert sizes1 == [6] and r0[4] == [3] and r1[4] == [3]
+    assert r0[1] == r1[1] == loss1              # cumulative (all-reduced) loss, integer valued
+    assert np.array_equal(r0[2], r1[2])         # replicas stay bit-identical
+    assert np.array_equal(r0[3], r1[3])         # both hold the all-reduced gradient
+    assert np.abs(r0[3] - grad1).max() <= 1e-5 * max(1.0, np.abs(grad1).max())
+    sure = np.abs(grad1) > 1e-4                 # Adam: +-lr steps where the gradient sign is decided
+    assert np.abs(r0[2] - flat1)[sure].max() < 5e-5

@@ -1,0 +1,185 @@
+"""Host-side logic of the drop-in API that needs no GPU: configuration, GraphExtender,
+graph handle and batch layout, checkpoints, training-loop bookkeeping, import roots."""
+import copy
+import os
+import pickle
+
+import networkx as nx
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle as CO
+from oracle import ref_dense as R
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def T(built):
+    from gcn_max_cut_amd.Training import TrainingNeural
+    return TrainingNeural
+
+
+def test_training_config_defaults_and_derived_fields(T):
+    c = T.TrainingConfig()
+    assert (c.n_nodes, c.dim_embedding, c.hidden_dim, c.number_classes) == (1000, 1000, 500, 3)
+    assert (c.learning_rate, c.number_epochs, c.tolerance, c.patience) == (0.001, 1000, 1e-4, 20)
+    assert (c.prob_threshold, c.A, c.C, c.penalty, c.save_directory, c.save_frequency) == (0.5, 0.0, 1.0, 1000.0, None, 100)
+    c = T.TrainingConfig(n_nodes=4096)
+    assert c.dim_embedding == 4096 and c.hidden_dim == 2048
+    assert [f for f in c.__dataclass_fields__] == [
+        "n_nodes", "dim_embedding", "hidden_dim", "dropout", "number_classes", "learning_rate", "number_epochs",
+        "tolerance", "patience", "prob_threshold", "A", "C", "penalty", "save_directory", "save_frequency"]
+
+
+def test_model_layout_matches_dgl_graphconv(T):
+    net, embed, opt = T.setup_model_and_optimizer(T.TrainingConfig())
+    sd = net.state_dict()
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {
+        "conv1.weight": (1000, 500), "conv1.bias": (500,), "conv2.weight": (500, 3), "conv2.bias": (3,)}
+    assert sum(p.numel() for p in net.parameters()) == 502003
+    assert float(sd["conv1.bias"].abs().max()) == 0.0
+    assert float(sd["conv1.weight"].abs().max()) <= (6 / 1500) ** 0.5 + 1e-7   # xavier-uniform bound
+    assert tuple(embed.weight.shape) == (1000, 1000)
+    assert len(opt.param_groups[0]["params"]) == 5       # the unused embedding is in the optimizer (Q1)
+
+
+def test_graph_extender_matches_oracle_and_keeps_reference_quirks(built, tmp_path, monkeypatch):
+    from gcn_max_cut_amd.DataGenerator import graphExtender as GE
+    monkeypatch.chdir(tmp_path)
+    specs = [(40, 5, 11), (30, 4, 12), (36, 6, 13)]
+    graphs, terms = util.make_graphs(specs)
+    terms = {0: [5, 9, 11], 1: [2, 7, 9], 2: [0, 1, 5]}          # case 1, case 2, skipped
+    g2, t2 = copy.deepcopy(graphs), copy.deepcopy(terms)
+    ds = GE.process_graphs_from_folder(graphs, terms, 1000)
+    ods = R.make_dataset(g2, t2, 1000)
+    assert list(ds) == list(ods) == [0, 1]
+    for k in ds:
+        h, a_pad, nx_g, t = ds[k]
+        og, oa, onx, ot = ods[k]
+        assert t == ot == [0, 1, 2] and a_pad.dtype == torch.float32
+        assert torch.equal(a_pad.cpu(), oa)
+        assert h.number_of_nodes() == og.n and h.number_of_edges() == og.number_of_edges() == 2 * nx_g.number_of_edges()
+        assert sorted(map(sorted, nx_g.edges())) == sorted(map(sorted, onx.edges()))
+        rp, cl, _ = CO.csr_of(nx_g)
+        assert np.array_equal(h.rowptr, rp) and np.array_equal(h.col, cl)
+    assert graphs[0] is ds[0][2]                      # caller's graph relabelled in place (Q11)
+    assert terms[1] == [2, 7, 9] and terms[1] is not None
+    # batch flush resets the returned dict (Q11)
+    graphs, terms = util.make_graphs(specs)
+    out = GE.process_graphs_from_folder(graphs, {0: [5, 9, 11], 1: [6, 7, 9], 2: [4, 8, 9]}, 1000,
+                                        save_batch_size=2, output_filename_prefix="flush")
+    assert list(out) == [2] and os.path.exists("flush_2.pkl")
+    assert list(pickle.load(open("flush_2.pkl", "rb"))) == [0, 1]
+    with pytest.raises(ValueError):
+        GE.extend_matrix_torch_2(torch.zeros(5, 5), 3)
+
+
+def test_graph_handle_pickles_and_answers_like_a_dgl_graph(built):
+    g = R.regular_graph(50, 6, 3)
+    h = built.from_networkx(g).to("cpu")
+    h2 = pickle.loads(pickle.dumps(h))
+    assert h2.number_of_nodes() == 50 and h2.number_of_edges() == 300
+    assert np.array_equal(h2.col, h.col) and int(h.in_degrees().sum()) == 300
+    src, dst = h.edges()
+    assert sorted(zip(src.tolist(), dst.tolist())) == sorted([(u, v) for u, v in g.edges()] + [(v, u) for u, v in g.edges()])
+    # weighted graph: edge values follow the adjacency the model is called with
+    for u, v in g.edges():
+        g[u][v]["weight"] = 1 + (u + v) % 3
+    hw = built.from_networkx(g)
+    a = R.dense_adjacency(g, 1000)
+    vals = hw.edge_values(a)
+    assert vals is not None and np.array_equal(vals, hw.weight)
+    with pytest.raises(NotImplementedError):
+        bad = a.clone(); bad[0, 999] = 1.0
+        hw.edge_values(bad)
+    iso = nx.path_graph(4); iso.add_node(4)
+    with pytest.raises(built.DGLError):
+        built.from_networkx(iso).check_degrees()
+
+
+def test_batch_layout_csr_and_ell(built):
+    gs = [R.regular_graph(n, d, s) for n, d, s in [(30, 5, 1), (40, 8, 2), (24, 3, 3)]]
+    hs = [built.from_networkx(g) for g in gs]
+    b = built.BatchArrays(hs)
+    assert (b.B, b.R, b.nnz, b.n_max, b.uniform_n, b.ell_width) == (3, 94, 30 * 5 + 40 * 8 + 24 * 3, 40, 0, 8)
+    assert b.goff.tolist() == [0, 30, 70, 94]
+    for g, h in enumerate(hs):
+        r0 = int(b.goff[g])
+        for l in range(h.n):
+            e0, e1 = b.rowptr[r0 + l], b.rowptr[r0 + l + 1]
+            nb = h.col[h.rowptr[l]:h.rowptr[l + 1]]
+            assert np.array_equal(b.lcol[e0:e1], nb) and np.array_equal(b.gcol[e0:e1], nb + r0)
+            assert b.ell[r0 + l, :len(nb)].tolist() == nb.tolist()
+            assert (b.ell[r0 + l, len(nb):] == h.n).all()          # padded with the zero row's id
+            assert b.dinv[r0 + l] == np.float32(1.0) / np.sqrt(np.float32(len(nb)))
+    assert b.vals is None and b.ell_vals is None
+    assert built.BatchArrays([hs[0], hs[0]]).uniform_n == 30
+    big = built.from_networkx(nx.random_regular_graph(20, 64, seed=1))
+    assert built.BatchArrays([big]).ell is None                     # degree > 16: row kernels only
+
+
+def test_early_stopping_best_tracking_and_checkpoints(T, tmp_path, monkeypatch):
+    """train_model's bookkeeping (TrainingNeural.py:421-482) with a scripted loss sequence."""
+    monkeypatch.chdir(tmp_path)
+    losses = iter([-10.0, -9.0, -8.0, -7.0, -20.0, -30.0])
+    monkeypatch.setattr(T, "train_single_epoch", lambda *a, **k: next(losses))
+    cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=8, number_epochs=6, patience=3, save_directory="m.pth", save_frequency=2)
+    net, best, epoch, emb, hist = T.train_model({}, cfg)
+    ref_stop, ref_best, ref_hist = R.early_stop_trace([-10.0, -9.0, -8.0, -7.0, -20.0, -30.0], cfg.tolerance, cfg.patience)
+    assert (epoch, best, hist) == (ref_stop, ref_best, ref_hist) == (3, -10.0, [-10.0, -9.0, -8.0, -7.0])
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["epoch_0_loss_-10.0000_m.pth", "epoch_2_loss_-8.0000_m.pth", "final_m.pth"]   # Q9 names
+    ck = torch.load("final_m.pth", weights_only=False)
+    assert set(ck) == {"epoch", "model", "optimizer", "loss_history", "inputs", "config"}
+    assert ck["config"].hidden_dim == 8 and tuple(ck["inputs"].shape) == (1000, 1000)
+    net2, inputs, cfg2 = T.load_neural_model("final_m.pth", cfg)
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), net2.state_dict()[k].cpu())
+    T.save_neural_model(net2, torch.optim.Adam(net2.parameters()), torch.nn.Embedding(4, 4), 7, [1.0], cfg, "again.pth")
+    assert torch.load("again.pth", weights_only=False)["epoch"] == 7
+    # README-style call: save_directory=None through kwargs -> nothing is saved (Q10)
+    losses = iter([-1.0])
+    monkeypatch.setattr(T, "open_file", lambda f: {})
+    T.train_from_pickle("whatever.pkl", "model_x", number_epochs=1, save_directory=None, hidden_dim=8)
+    assert not os.path.exists("final_model_x.pth")
+
+
+def test_loss_helpers_match_oracle_values_and_gradients(T):
+    ds = R.synthetic_dataset([(40, 5, 5)])
+    (g, a_pad, nx_g, _t), = ds.values()
+    torch.manual_seed(0)
+    p = torch.softmax(torch.randn(40, 3), dim=1).requires_grad_(True)
+    mine = T.compute_loss(T.apply_max_to_one_hot(T.override_fixed_nodes(p)), a_pad, 0, 2.0, 1000)
+    mine.backward()
+    p2 = p.detach().clone().requires_grad_(True)
+    ref = R.cut_loss(R.straight_through_one_hot(R.override_terminals(p2)), a_pad, 2.0)
+    ref.backward()
+    assert float(mine) == float(ref) and torch.allclose(p.grad, p2.grad, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        T.calculate_HC_vectorized(torch.eye(3)[:3], torch.zeros(3, 500))   # pad is hard-coded to 1000 (Q2)
+    with pytest.raises(ValueError):
+        T.extend_matrix_torch(torch.zeros(5, 5), 3)
+    assert T.get_gnn is T.get_gnn_legacy and T.LoadNeuralModel is T.load_neural_model
+    assert len(T.generate_terminal_permutations({"a": 0, "b": 1, "c": 2})) == 6
+
+
+def test_reference_import_roots_resolve_to_this_package(built):
+    built.install_compat()
+    import Training.TrainingNeural as A
+    import python.Training.TrainingNeural as B
+    import DataGenerator.graphExtender as G
+    import commons as Cm
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    assert A is T and B is T and hasattr(G, "process_graphs_from_folder") and hasattr(Cm, "open_file")
+    blob = pickle.dumps(A.TrainingConfig(hidden_dim=12))
+    assert pickle.loads(blob).hidden_dim == 12
+
+
+def test_sharding_helpers(built):
+    from gcn_max_cut_amd.engine import flat_layout, shard_for_rank
+    for n, w in [(160, 8), (20, 3), (5, 8), (0, 2)]:
+        parts = [list(shard_for_rank(n, r, w)) for r in range(w)]
+        assert sum(parts, []) == list(range(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+    offs, total = flat_layout(1000, 500, 3)
+    assert offs == [0, 500000, 500500, 502000, 502003] and total == 502003
