@@ -80,28 +80,22 @@ size_t lds_bytes(int n_max, int W, int FS) {  // + bias and W2 rows of up to kMa
     return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (size_t)kMaxSlicesPerWg * FS * 16;
 }
 
-// thread t owns float4 #(t + k*kThreads) of the tile = (row lrow + k*rows_per_pass, lane q):
-// exactly the (row, lane) pairs it later produces, so ACC registers hold one slice of them.
+// Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
+// #(t + k*kThreads) of the tile = (row lrow + k*rows_per_pass, lane q) - exactly the (row, lane)
+// pairs it later produces.  No VGPRs are involved; a wave's 64 x 16 B land contiguously at a
+// wave-uniform LDS base, which is precisely the [row][FS] order of the tile.  Completion is
+// covered by the vmcnt(0) that precedes the next __syncthreads().
 template <int FS, int ACC>
-__device__ __forceinline__ void prefetch_tile(const float *src_q, long ldx, int n, bool col_on, int lrow,
-                                              float4 (&pf)[ACC]) {
+__device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
     constexpr int kRowsPerPass = kThreads / (FS / 4);
+    const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
 #pragma unroll
     for (int k = 0; k < ACC; ++k) {
         const int l = lrow + k * kRowsPerPass;
-        pf[k] = gmc::f4_zero();
-        if (l < n && col_on) pf[k] = *reinterpret_cast<const float4 *>(src_q + (long)l * ldx);
-    }
-}
-
-template <int FS, int ACC>
-__device__ __forceinline__ void commit_tile(float *tile, int n, int lrow, int q, const float4 (&pf)[ACC]) {
-    constexpr int Q = FS / 4;
-    constexpr int kRowsPerPass = kThreads / Q;
-#pragma unroll
-    for (int k = 0; k < ACC; ++k) {
-        const int l = lrow + k * kRowsPerPass;
-        if (l < n) reinterpret_cast<float4 *>(tile)[l * Q + q] = pf[k];
+        if (l < n && col_on)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(src_q + (long)l * rs),
+                (__attribute__((address_space(3))) void *)(tile + 4 * (wave_base + k * kThreads)), 16, 0, 0);
     }
 }
 
@@ -119,11 +113,30 @@ __device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, fl
 }
 
 // sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
-template <int FS, int W, bool HAS_VAL>
+// LEAN: only 4 neighbour rows in flight (register-tight callers); same summation order.
+template <int FS, int W, bool HAS_VAL, bool LEAN = false>
 __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
                                              int l, int q) {
     constexpr int Q = FS / 4;
     float4 acc = gmc::f4_zero();
+    if (LEAN && !HAS_VAL) {
+#pragma unroll
+        for (int blk = 0; blk < W / 8; ++blk) {
+            const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
+            const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
+                                    ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[4 * h + u] * Q + q];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) gmc::f4_add(acc, x[u]);
+                asm volatile("" ::: "memory");  // finish this half before the next four loads
+            }
+        }
+        return acc;
+    }
 #pragma unroll
     for (int blk = 0; blk < W / 8; ++blk) {
         const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
@@ -153,7 +166,8 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
 //   stores of slice s-1 (held in registers)  ->  loads of slice s+1 (into registers)  ->
 //   LDS gather of slice s  ->  wait (loads s+1 done; stores s-1 long done)  ->
 //   write slice s+1 to the other LDS buffer  ->  barrier.
-template <int FS, int W, int ACC, bool EPI, bool HAS_VAL>
+// SHARED: the source is one table shared by every graph (W1 for the layer-1 feature transform)
+template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED>
 __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -172,10 +186,9 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     float *cw2 = cbias + per * FS;                                          // [per*FS][3] W2 rows of my columns
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
-    const float *src0 = a.X + (a.shared_src ? 0L : (long)r0 * a.x_rs) + 4 * q;
+    const float *src0 = a.X + (SHARED ? 0L : (long)r0 * a.x_rs) + 4 * q;
 
-    float4 pf[ACC];
-    prefetch_tile<FS, ACC>(src0 + s_beg * a.x_ss, a.x_rs, n, s_beg * FS + 4 * q < a.F, lrow, pf);
+    dma_tile<FS, ACC>(src0 + s_beg * a.x_ss, a.x_rs, n, s_beg * FS + 4 * q < a.F, lrow, lds);
 
     float zr[EPI ? ACC : 1][3] = {};
     float sc[ACC];
@@ -193,7 +206,6 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         }
     }
     load_table<FS, W>(a.b, r0, n, lds, lds + TF, nb);
-    commit_tile<FS, ACC>(lds, n, lrow, q, pf);
     __syncthreads();
 
     float4 y[ACC];
@@ -202,26 +214,25 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         const float *tile = lds + cur * TF;
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
-        float w2[EPI ? 12 : 1];
-        if (EPI) {
-#pragma unroll
-            for (int j = 0; j < 12; ++j) w2[j] = cw2[3 * cl + j];
-        }
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);  // rows past the end redo row n-1 (never stored)
             float4 acc = gmc::f4_zero();
-            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL, EPI>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
             y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
             y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
             if (a.relu) {
                 y[k].x = y[k].x > 0.f ? y[k].x : 0.f; y[k].y = y[k].y > 0.f ? y[k].y : 0.f;
                 y[k].z = y[k].z > 0.f ? y[k].z : 0.f; y[k].w = y[k].w > 0.f ? y[k].w : 0.f;
             }
-            if (EPI) {  // columns past F carry w2 = 0
-                zr[k][0] += y[k].x * w2[0] + y[k].y * w2[3] + y[k].z * w2[6] + y[k].w * w2[9];
-                zr[k][1] += y[k].x * w2[1] + y[k].y * w2[4] + y[k].z * w2[7] + y[k].w * w2[10];
-                zr[k][2] += y[k].x * w2[2] + y[k].y * w2[5] + y[k].z * w2[8] + y[k].w * w2[11];
+            if (EPI) {  // W2 rows of my 4 columns from LDS; pad columns (>= F) may hold anything
+                if (s * FS + 4 * q >= a.F) y[k] = gmc::f4_zero();
+                const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
+                const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
+                const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+                zr[k][0] += y[k].x * wa.x + y[k].y * wa.w + y[k].z * wb.z + y[k].w * wc.y;
+                zr[k][1] += y[k].x * wa.y + y[k].y * wb.x + y[k].z * wb.w + y[k].w * wc.z;
+                zr[k][2] += y[k].x * wa.z + y[k].y * wb.y + y[k].z * wc.x + y[k].w * wc.w;
             }
         }
     };
@@ -234,24 +245,23 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
                 *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)s * a.y_ss + 4 * q) = y[k];
         }
     };
-    auto prefetch = [&](int s) {  // clamped: past the last slice re-read it (L2 hit, never used)
+    auto prefetch = [&](int s, int into) {  // clamped: past the last slice re-read it (L2 hit, never used)
         const int sc_ = min(s, s_end - 1);
-        prefetch_tile<FS, ACC>(src0 + sc_ * a.x_ss, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, pf);
+        dma_tile<FS, ACC>(src0 + sc_ * a.x_ss, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, lds + into * TF);
     };
 
-    // peeled first slice, then a branch-free steady state
-    prefetch(s_beg + 1);
+    // peeled first slice, then the steady state: DMA of slice s+1 and stores of slice s-1 are
+    // issued first, the LDS gather of slice s runs while they are in flight, and the barrier's
+    // vmcnt(0) retires them
+    prefetch(s_beg + 1, 1);
     compute(s_beg, 0);
-    commit_tile<FS, ACC>(lds + TF, n, lrow, q, pf);
     __syncthreads();
     for (int s = s_beg + 1; s < s_end; ++s) {
         const int cur = (s - s_beg) & 1;
-        prefetch(s + 1);   // loads of the next slice: in flight during the gather below
-        store(s - 1);      // stores of the previous slice: complete during the gather below
-        asm volatile("" ::: "memory");  // keep every load and store above ahead of the gather
+        prefetch(s + 1, cur ^ 1);
+        store(s - 1);
         compute(s, cur);
-        commit_tile<FS, ACC>(lds + (cur ^ 1) * TF, n, lrow, q, pf);
-        __syncthreads();   // next tile complete; everyone is done reading this one
+        __syncthreads();   // next tile landed; everyone is done reading this one
     }
     store(s_end - 1);
     if (EPI) {  // fold the row's Q lanes (fixed xor tree), one partial per slice group
@@ -296,17 +306,17 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const int c0 = s * FS;
     const bool col_on = c0 + 4 * q < a.F;
-    float4 acc[ACC], pf[ACC];
+    float4 acc[ACC];
     uint4 pt[NT];
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = gmc::f4_zero();
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
-    auto fetch = [&](int g) {  // tile slice + neighbour table of graph g -> registers
+    auto fetch = [&](int g, int into) {  // tile slice -> LDS buffer `into` (DMA); neighbour table -> registers
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
-        prefetch_tile<FS, ACC>(a.U + (long)r0 * a.u_rs + (long)s * a.u_ss + 4 * q, a.u_rs, n, col_on, lrow, pf);
+        dma_tile<FS, ACC>(a.U + (long)r0 * a.u_rs + (long)s * a.u_ss + 4 * q, a.u_rs, n, col_on, lrow, lds + into * TF);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
@@ -321,10 +331,9 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
             if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
         }
     };
-    fetch(g0);
+    fetch(g0, 0);
     {
         const int n = a.b.goff[g0 + 1] - a.b.goff[g0];
-        commit_tile<FS, ACC>(lds, n, lrow, q, pf);
         commit_table(n);
         if (threadIdx.x < FS) lds[n * FS + threadIdx.x] = 0.f;
     }
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
         const int cur = (g - g0) & 1;
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
-        if (g + 1 < g1) fetch(g + 1);
+        if (g + 1 < g1) fetch(g + 1, cur ^ 1);
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -342,7 +351,6 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
         }
         if (g + 1 < g1) {
             const int n1 = a.b.goff[g + 2] - a.b.goff[g + 1];
-            commit_tile<FS, ACC>(lds + (cur ^ 1) * TF, n1, lrow, q, pf);
             if (threadIdx.x < FS) lds[(cur ^ 1) * TF + n1 * FS + threadIdx.x] = 0.f;
             __syncthreads();  // everyone is done with graph g's table
             commit_table(n1);
@@ -382,12 +390,15 @@ int launch_spmm(const TileArgs &a, size_t lds, hipStream_t st) {
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
     const int grid = a.b.B * a.groups;
     const bool epi = a.Zpart != nullptr;
-#define GMC_PICK(AC)                                                                                   \
-    do {                                                                                               \
-        if (a.use_vals) return epi ? launch(spmm_lds_kernel<FS, W, AC, true, true>, grid, lds, st, a)   \
-                                   : launch(spmm_lds_kernel<FS, W, AC, false, true>, grid, lds, st, a); \
-        return epi ? launch(spmm_lds_kernel<FS, W, AC, true, false>, grid, lds, st, a)                  \
-                   : launch(spmm_lds_kernel<FS, W, AC, false, false>, grid, lds, st, a);                \
+#define GMC_PICK(AC)                                                                                          \
+    do {                                                                                                      \
+        if (a.shared_src)  /* W1 gather: weights apply, never fused with W2 */                               \
+            return a.use_vals ? launch(spmm_lds_kernel<FS, W, AC, false, true, true>, grid, lds, st, a)       \
+                              : launch(spmm_lds_kernel<FS, W, AC, false, false, true>, grid, lds, st, a);     \
+        if (a.use_vals) return epi ? launch(spmm_lds_kernel<FS, W, AC, true, true, false>, grid, lds, st, a)  \
+                                   : launch(spmm_lds_kernel<FS, W, AC, false, true, false>, grid, lds, st, a);\
+        return epi ? launch(spmm_lds_kernel<FS, W, AC, true, false, false>, grid, lds, st, a)                 \
+                   : launch(spmm_lds_kernel<FS, W, AC, false, false, false>, grid, lds, st, a);               \
     } while (0)
     if (acc <= 4) GMC_PICK(4);
     if (acc <= 8) GMC_PICK(8);
