@@ -10,6 +10,10 @@ int gmc_hidden_slab_tiles(int R);
 int gmc_hidden_bwd_slab_launch(const float *, const float *, const float *, const float *, float *, float *, int,
                                int, int, hipStream_t);
 int gmc_lds_slice_width(const gmc_batch *b);
+int gmc_dw1_chunks(int B, bool lds);
+int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
+int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
+                        int, hipStream_t);
 int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
                           long, float *, int, int, hipStream_t);
 int gmc_colsum_reduce_launch(const float *, int, int, float *, float *, const float *, int, float *,
@@ -48,6 +52,12 @@ bool use_lds(const gmc_batch *b) {
     return gmc_lds_fits(b);
 }
 
+// GMC_FUSE=0 keeps the unfused kernel sequence (A/B runs recorded under profiles/)
+bool fuse_enabled() {
+    static const bool on = [] { const char *e = getenv("GMC_FUSE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 
 Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base) {
@@ -68,7 +78,9 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     w.Z0 = take((size_t)w.zparts * R * 3);
     if (training) {
         w.GY2 = take(R * 3);
-        w.part = take((size_t)(w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R)) * F * 4);
+        size_t tiles = w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R);
+        if (w.fs && (size_t)gmc_dw1_chunks(b->B, true) > tiles) tiles = gmc_dw1_chunks(b->B, true);
+        w.part = take(tiles * F * 4);
         w.db2part = take((size_t)b->B * 3);
         w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
     }
@@ -118,6 +130,14 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
+    if (w.fs && fuse_enabled()) {  // one pass over H: Gs and U live only in LDS
+        const int chunks = gmc_dw1_chunks(b->B, true), per = (b->B + chunks - 1) / chunks;
+        int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
+        if (rc) return rc;
+        rc = gmc_colsum_reduce_launch(w.part, chunks, m->F, dW2, db1, w.db2part, b->B, db2, st);
+        if (rc) return rc;
+        return gmc_fold_chunks_launch(w.dw1part, dW1, m->N, b->n_max, m->F, chunks, st);
+    }
     int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, m->W2, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
                   : gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
     if (rc) return rc;

@@ -106,12 +106,24 @@ __global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, fl
 bool gmc_lds_fits(const gmc_batch *b);
 int gmc_dw1_lds_launch(const gmc_batch *, const float *, long, int, float *, int, int, int, hipStream_t);
 
+int gmc_fold_chunks_launch(const float *scratch, float *dW1, int N, int rows, int F, int chunks, hipStream_t st) {
+    GmcProbeScope probe(GMC_K_DW1_FOLD, st);
+    const long n4 = (long)N * F / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(fold_chunks_kernel, dim3(blocks), dim3(256), 0, st,
+                       reinterpret_cast<const float4 *>(scratch), reinterpret_cast<float4 *>(dW1), N, rows,
+                       F / 4, chunks);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
 // chunks the batch is split into for parallelism
 int gmc_dw1_chunks(int B, bool lds) {
-    if (lds) {  // (slice, chunk) workgroups: ~16-32 slices x chunks should fill 512 slots
-        int c = (B + 7) / 8;
+    if (lds) {  // (slice, chunk) workgroups, one per CU: aim at ~512 (two even rounds of 256 CUs
+                // at 32 slices) without letting the [chunks][n_max][F] partials grow large
+        int c = B < 16 ? B : 16;
         if (c < 1) c = 1;
-        return c > 32 ? 32 : c;
+        return c;
     }
     if (B <= 4) return 1;
     const int c = (B + 7) / 8;  // ~8 graphs per wave: 1000 rows x chunks waves

@@ -76,8 +76,10 @@ __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
 // neighbour table [n_max][W] of 16-bit ids.
 __host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + 1) * FS; }
 constexpr int kMaxSlicesPerWg = 8;
-size_t lds_bytes(int n_max, int W, int FS) {  // + bias and W2 rows of up to kMaxSlicesPerWg slices
-    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (size_t)kMaxSlicesPerWg * FS * 16;
+size_t lds_bytes(int n_max, int W, int FS) {
+    // + the larger of: bias and W2 rows of up to kMaxSlicesPerWg slices (spmm: 8 * FS * 16 B) and
+    // the cross-wave fold area of bwd1 (16 waves * FS/4 lanes * 16 floats = 256 * FS B)
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (size_t)256 * FS;
 }
 
 // Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
@@ -366,6 +368,170 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
     }
 }
 
+// ---- fused layer-1 backward: hidden backward + aggregation + dW1 in one pass over H --------
+//
+// Workgroup = (column slice, chunk of graphs).  Per graph: the H tile arrives by LDS-DMA; every
+// thread turns its own elements into Gs = dinv^2 o relu'(H) o (GY2 @ W2^T) IN PLACE (and adds
+// their dW2 / db1 terms to register partials); gather #1 builds the U tile = dinv o (A @ Gs) in
+// the second LDS buffer; the next graph's H tile is then DMA'd into the first buffer while
+// gather #2 accumulates dW1 += A_val @ U in registers.  Gs and U never exist in HBM: the whole
+// backward of layer 1 (autograd of TrainingNeural.py:80-83, run by loss.backward() :385)
+// reads H once.  Outputs: dW1 partial [chunk][n_max][F] and column partials [chunk][F][4]
+// = (dW2[f,0..2], db1[f]), folded in chunk order by fold_chunks / colsum_reduce.
+struct Bwd1Args {
+    gmc_batch b;
+    const float *H;       // slab layout [slice][R][FS]
+    const float *GY2;     // [R][3]
+    const float *W2;      // [F][3]
+    float *dw1part;       // [chunks][n_max][F]
+    float *colpart;       // [chunks][F][4]
+    int F;
+    int slices;
+    int chunks;
+    int graphs_per_chunk;
+};
+
+template <int FS, int W, int ACC, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;
+    int chunk, s;
+    tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    float *bufA = lds, *bufB = lds + TF;
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
+    float *red = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [16 waves][Q][16]
+    const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+    const int f0 = s * FS + 4 * q;
+    const bool col_on = f0 < a.F;
+    const long slab = (long)s * a.b.R * FS;
+    float w2[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) w2[j][k] = col_on ? a.W2[(long)(f0 + j) * 3 + k] : 0.f;
+    float4 acc[ACC];
+    float colp[16] = {};  // [j][0..2] dW2, [j][3] db1 for my 4 columns
+    uint4 pt[NT];
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) acc[k] = gmc::f4_zero();
+
+    const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
+    if (g0 >= g1) return;
+    auto fetch = [&](int g) {  // H tile -> bufA (DMA); neighbour table -> registers
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
+        dma_tile<FS, ACC>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit_table = [&](int n) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+        }
+        if (threadIdx.x < FS) {
+            bufA[n * FS + threadIdx.x] = 0.f;
+            bufB[n * FS + threadIdx.x] = 0.f;
+        }
+    };
+    fetch(g0);
+    commit_table(a.b.goff[g0 + 1] - a.b.goff[g0]);
+    __syncthreads();
+    for (int g = g0; g < g1; ++g) {
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
+        float dv[ACC];
+        // (1) H -> Gs in place + column partials
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            dv[k] = 1.f;
+            if (l < n) {
+                const int r = r0 + l;
+                const float d = a.b.dinv[r];
+                dv[k] = d;
+                const float gy0 = a.GY2[(long)r * 3], gy1 = a.GY2[(long)r * 3 + 1], gy2 = a.GY2[(long)r * 3 + 2];
+                float4 *cell = reinterpret_cast<float4 *>(bufA) + l * Q + q;
+                const float4 h = *cell;
+                const float hv[4] = {h.x, h.y, h.z, h.w};
+                float gs[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gh = gy0 * w2[j][0] + gy1 * w2[j][1] + gy2 * w2[j][2];
+                    const float gpre = (col_on && hv[j] > 0.f) ? gh * d : 0.f;
+                    gs[j] = gpre * d;
+                    const float hd = col_on ? hv[j] * d : 0.f;
+                    colp[4 * j + 0] = fmaf(hd, gy0, colp[4 * j + 0]);
+                    colp[4 * j + 1] = fmaf(hd, gy1, colp[4 * j + 1]);
+                    colp[4 * j + 2] = fmaf(hd, gy2, colp[4 * j + 2]);
+                    colp[4 * j + 3] += gpre;
+                }
+                *cell = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            }
+        }
+        __syncthreads();
+        // (2) U tile = dinv o (A @ Gs)
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n) {
+                float4 u = gather_row<FS, W, false>(bufA, nb, nullptr, l, q);
+                u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
+                reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+            }
+        }
+        __syncthreads();
+        // (3) next graph's H tile streams into bufA while (4) gathers from bufB
+        if (g + 1 < g1) fetch(g + 1);
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+        }
+        __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
+        if (g + 1 < g1) commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
+        __syncthreads();
+    }
+    if (col_on) {
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = acc[k];
+        }
+    }
+    // column partials: fold the lanes sharing q inside each wave, then the 16 waves (fixed order)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 32; o >= Q; o >>= 1) colp[i] += __shfl_xor(colp[i], o, GMC_WAVE);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < Q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wave * Q + lane) * 16 + i] = colp[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q * 4) {  // thread = (q, j): column f = s*FS + 4q + j
+        const int qq = threadIdx.x / 4, j = threadIdx.x % 4;
+        if (s * FS + 4 * qq < a.F) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int wv = 0; wv < kThreads / 64; ++wv)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] += red[(wv * Q + qq) * 16 + 4 * j + c];
+            reinterpret_cast<float4 *>(a.colpart)[(long)chunk * a.F + s * FS + 4 * qq + j] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 // Slice width for graphs of up to n_max nodes with W neighbour slots: the widest slice whose
 // two tile buffers + table fit the CU's 160 KiB of LDS; 0 = does not fit (row kernels).
 int pick_fs(int n_max, int W) {
@@ -475,6 +641,43 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int x_slab
         case 64: return launch_spmm<64, 16>(a, lds, st);
         case 32: return launch_spmm<32, 16>(a, lds, st);
         default: return launch_spmm<16, 16>(a, lds, st);
+    }
+}
+
+template <int FS, int W>
+int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
+    constexpr int rows_per_pass = kThreads / (FS / 4);
+    const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
+    const int grid = a.slices * a.chunks;
+    const bool hv = a.b.ell_vals != nullptr;
+    if (acc <= 4) return hv ? launch(bwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
+                            : launch(bwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
+    if (acc <= 8) return hv ? launch(bwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
+                            : launch(bwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    return GMC_ERR_UNSUPPORTED;
+}
+
+// fused layer-1 backward over the slab-layout H: dW1 partials [chunks][n_max][F] and column
+// partials [chunks][F][4] (dW2, db1)
+int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, const float *W2,
+                        float *dw1part, float *colpart, int F, int chunks, int graphs_per_chunk,
+                        hipStream_t st) {
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    GmcProbeScope probe(GMC_K_BWD1_FUSED, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_bwd1<64, 8>(a, lds, st);
+            case 32: return launch_bwd1<32, 8>(a, lds, st);
+            default: return launch_bwd1<16, 8>(a, lds, st);
+        }
+    }
+    switch (fs) {
+        case 64: return launch_bwd1<64, 16>(a, lds, st);
+        case 32: return launch_bwd1<32, 16>(a, lds, st);
+        default: return launch_bwd1<16, 16>(a, lds, st);
     }
 }
 

@@ -120,7 +120,7 @@ def stream() -> int:
 
 
 KERNEL_TAGS = ("gather_w1", "agg_fwd", "head", "hidden_bwd", "colsum", "agg_bwd", "dw1", "dw1_fold",
-               "adam", "spmm_user", "dense_mfma")
+               "adam", "spmm_user", "dense_mfma", "bwd1_fused", "fwd1_fused")
 
 
 class Probe:

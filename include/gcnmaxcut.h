@@ -94,7 +94,9 @@ enum {
     GMC_K_ADAM = 8,       /* fused Adam                                      :386 */
     GMC_K_SPMM_USER = 9,  /* gmc_spmm_f32 called directly */
     GMC_K_DENSE_MFMA = 10,
-    GMC_K_COUNT = 11
+    GMC_K_BWD1_FUSED = 11, /* hidden backward + conv1 backward aggregation + dW1, one pass over H */
+    GMC_K_FWD1_FUSED = 12, /* W1 gather + layer-1 aggregation (+ fused H@W2), one kernel */
+    GMC_K_COUNT = 13
 };
 
 /* Timing probe for bench.py: between gmc_probe_begin and gmc_probe_end every kernel launch
