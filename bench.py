@@ -13,10 +13,13 @@ n=1000 d=7 graphs (R = 160,000 rows, 646 MB algorithmic bytes per F=500 SpMM, be
 processes N*160 graphs per step; `value` counts epochs of 160 graphs per second.
 
 The JSON line also carries
-  roofline     - the dominant kernel (row-per-wave CSR SpMM of the layer-1 aggregation,
-                 forward + backward launches): algorithmic bytes / mean launch duration,
-                 durations from HIP events recorded by the library on the launch stream
-                 during the timed steps;
+  roofline     - the SpMM the metric names (LDS-tiled CSR SpMM of the layer-1 aggregation,
+                 forward + backward launches): algorithmic bytes / mean launch duration, HIP
+                 events recorded by the library on the launch stream during a second timed
+                 region of K steps run as one kernel per operation (gmc_set_fuse(0));
+  roofline_fused - the two dominant kernels of the default (fused) step, from the HIP
+                 events of the main timed region: compulsory bytes (what the fused kernel must
+                 move) and the unfused bytes SURVEY section 8d prices for the operations it replaces;
   cpu_baseline - the CPU oracle (oracle/ref_dense.py, reference-structured torch-CPU port:
                  dense [n,1000] GEMM, per-row Python one-hot, dense loss, one Adam step per
                  graph) timed on this box's host cores on a bounded sample, rank 0, N=1 only.
@@ -171,7 +174,36 @@ def main():
         "kernels_ms": {k: round(v, 5) for k, v in sorted(kmean.items())},
     }
 
-    spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in kernels.get(tag, [])]
+    R_, F_, N_ = gpg * n, args.hidden, 1000
+    fused = {}
+    for tag, compulsory, unfused_mb in (
+            ("fwd1_fused", R_ * F_ * 4 + N_ * F_ * 4 + R_ * 16 + R_ * 12 * 8, 10.0),   # H write, W1, table, Zpart
+            ("bwd1_fused", R_ * F_ * 4 + R_ * 16 + R_ * 16 + 16 * N_ * F_ * 4, 12.0)):  # H read, GY2+dinv, table, dW1 partials
+        if tag in kmean:
+            dur = kmean[tag] * 1e-3
+            fused[tag] = {"mean_launch_us": dur * 1e6, "compulsory_bytes_per_launch": compulsory,
+                          "compulsory_GBps": compulsory / dur / 1e9,
+                          "survey_unfused_bytes_per_launch": int(unfused_mb * 1e6 * gpg),
+                          "survey_unfused_GBps": unfused_mb * 1e6 * gpg / dur / 1e9}
+    out["roofline_fused"] = fused or None
+
+    # second timed region: the same step as one kernel per operation -> the stand-alone SpMM
+    spmm = []
+    if args.mode == "batched" and not args.no_probe:
+        lib = pkg.hip.load()
+        prev = lib.gmc_set_fuse(0)
+        for _ in range(2):
+            trainer.epoch(dataset)
+        with pkg.hip.Probe(launches_per_step * args.steps) as p2:
+            for _ in range(args.steps):
+                trainer.epoch(dataset)
+            torch.cuda.synchronize()
+        lib.gmc_set_fuse(prev)
+        k2 = {}
+        for tag, ms in p2.records:
+            k2.setdefault(tag, []).append(ms)
+        out["kernels_ms_unfused"] = {k: round(float(np.mean(v)), 5) for k, v in sorted(k2.items())}
+        spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in k2.get(tag, [])]
     if spmm and args.mode == "batched":
         dur = float(np.mean(spmm)) * 1e-3
         achieved = spmm_bytes / dur / 1e9
@@ -182,7 +214,7 @@ def main():
             if rec.get("rows") == gpg * n and rec.get("F") == args.hidden:
                 traffic = rec.get("hbm_bytes_per_launch")
         out["roofline"] = {
-            "kernel": "spmm_rows_v4 (layer-1 aggregation, fwd + bwd launches)",
+            "kernel": "spmm_lds_kernel (layer-1 aggregation SpMM, fwd + bwd launches; one-kernel-per-op leg)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": spmm_bytes, "mean_launch_us": dur * 1e6,

@@ -12,6 +12,8 @@ int gmc_hidden_bwd_slab_launch(const float *, const float *, const float *, cons
 int gmc_lds_slice_width(const gmc_batch *b);
 int gmc_dw1_chunks(int B, bool lds);
 int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
+int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
+                        hipStream_t);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
                         int, hipStream_t);
 int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
@@ -52,10 +54,12 @@ bool use_lds(const gmc_batch *b) {
     return gmc_lds_fits(b);
 }
 
-// GMC_FUSE=0 keeps the unfused kernel sequence (A/B runs recorded under profiles/)
+// Fused layer kernels (default) vs the one-kernel-per-op sequence; GMC_FUSE=0 or gmc_set_fuse(0)
+// selects the latter (bench.py times the stand-alone SpMM kernel that way).
+int g_fuse = -1;
 bool fuse_enabled() {
-    static const bool on = [] { const char *e = getenv("GMC_FUSE"); return !(e && e[0] == '0'); }();
-    return on;
+    if (g_fuse < 0) { const char *e = getenv("GMC_FUSE"); g_fuse = (e && e[0] == '0') ? 0 : 1; }
+    return g_fuse != 0;
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -115,6 +119,8 @@ int aggregate(const gmc_batch *b, const Workspace &w, const float *X, float *Y, 
 
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
     const int F = m->F;
+    if (w.fs && fuse_enabled())  // T0 lives only in LDS
+        return gmc_fwd1_lds_launch(b, m->W1, m->b1, m->W2, w.H, w.Z0, F, st);
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
     int rc = w.fs ? gmc_spmm_lds_launch(b, m->W1, F, 0, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, 1, F, nullptr,
                                         nullptr, GMC_K_GATHER_W1, st)
@@ -207,6 +213,12 @@ extern "C" int gmc_probe_end(int32_t *tags, float *ms, int32_t max) {
         if (ms) ms[i] = t;
     }
     return n;
+}
+
+extern "C" int gmc_set_fuse(int on) {
+    const int prev = fuse_enabled() ? 1 : 0;
+    g_fuse = on ? 1 : 0;
+    return prev;
 }
 
 extern "C" int gmc_version(void) { return GMC_VERSION; }

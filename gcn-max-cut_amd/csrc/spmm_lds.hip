@@ -85,19 +85,28 @@ size_t lds_bytes(int n_max, int W, int FS) {
 // Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
 // #(t + k*kThreads) of the tile = (row lrow + k*rows_per_pass, lane q) - exactly the (row, lane)
 // pairs it later produces.  No VGPRs are involved; a wave's 64 x 16 B land contiguously at a
-// wave-uniform LDS base, which is precisely the [row][FS] order of the tile.  Completion is
-// covered by the vmcnt(0) that precedes the next __syncthreads().
+// wave-uniform LDS base, which is precisely the [row][FS] order of the tile.
+//
+// Issued through inline asm so hipcc does not see an LDS write: with the builtin it drains
+// vmcnt(0) before the next ds_read (it cannot prove the gather reads the OTHER buffer), which
+// serialises the DMA against the gather it is meant to overlap.  The price: completion is
+// ours to wait for - dma_wait() before the barrier that precedes the first read of the tile.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 template <int FS, int ACC>
 __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
     constexpr int kRowsPerPass = kThreads / (FS / 4);
-    const int wave_base = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tile;
+    const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (threadIdx.x & ~63u)));
 #pragma unroll
     for (int k = 0; k < ACC; ++k) {
         const int l = lrow + k * kRowsPerPass;
-        if (l < n && col_on)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void *)(src_q + (long)l * rs),
-                (__attribute__((address_space(3))) void *)(tile + 4 * (wave_base + k * kThreads)), 16, 0, 0);
+        if (l < n && col_on) glds16(src_q + (long)l * rs, wave_dst + 16u * (unsigned)(k * kThreads));
     }
 }
 
@@ -208,6 +217,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         }
     }
     load_table<FS, W>(a.b, r0, n, lds, lds + TF, nb);
+    dma_wait();
     __syncthreads();
 
     float4 y[ACC];
@@ -257,12 +267,14 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     // vmcnt(0) retires them
     prefetch(s_beg + 1, 1);
     compute(s_beg, 0);
+    dma_wait();
     __syncthreads();
     for (int s = s_beg + 1; s < s_end; ++s) {
         const int cur = (s - s_beg) & 1;
         prefetch(s + 1, cur ^ 1);
         store(s - 1);
         compute(s, cur);
+        dma_wait();
         __syncthreads();   // next tile landed; everyone is done reading this one
     }
     store(s_end - 1);
@@ -334,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
         }
     };
     fetch(g0, 0);
+    dma_wait();
     {
         const int n = a.b.goff[g0 + 1] - a.b.goff[g0];
         commit_table(n);
@@ -357,6 +370,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
             __syncthreads();  // everyone is done with graph g's table
             commit_table(n1);
         }
+        dma_wait();
         __syncthreads();
     }
     if (col_on) {
@@ -364,6 +378,130 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.out + ((long)chunk * a.b.n_max + l) * a.F + c0 + 4 * q) = acc[k];
+        }
+    }
+}
+
+// ---- fused layer-1 forward: W1 row gather + aggregation (+ fused H@W2) in one kernel ---------
+//
+// Workgroup = (graph, slice group).  Per slice: the W1 slice (rows 0..n-1 of the shared
+// [N,F] table, L2-resident) arrives in buffer A by LDS-DMA; gather #1 builds the T0 tile =
+// dinv o (A_val @ W1[:n]) in buffer B (the X@W1 of TrainingNeural.py:80 with X = padded
+// adjacency, :373); the next slice's W1 tile is then DMA'd into A while gather #2 produces
+// H = relu(dinv o (A @ T0) + b1) (:80-81) from B, with the layer-2 feature transform
+// (H o dinv) @ W2 (:83) accumulated in registers.  T0 never exists in HBM: the forward of layer 1
+// writes H once and reads only W1 (from L2) and the neighbour table.
+template <int FS, int W, int ACC, bool HAS_VAL>
+__global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+    int g, grp;
+    tile_of((int)blockIdx.x, a.b.B, a.groups, g, grp);
+    const int r0 = a.b.goff[g];
+    const int n = a.b.goff[g + 1] - r0;
+    const int per = (a.slices + a.groups - 1) / a.groups;
+    const int s_beg = grp * per, s_end = min(a.slices, s_beg + per);
+    if (s_beg >= s_end) return;
+
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    float *bufA = lds, *bufB = lds + TF;
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
+    float *cbias = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);
+    float *cw2 = cbias + per * FS;
+    const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+    const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+    const float *src0 = a.X + 4 * q;  // W1, row-major [N][ldx]
+
+    auto dma = [&](int s) {  // clamped past the last slice (L2 hit, never used)
+        const int sc_ = min(s, s_end - 1);
+        dma_tile<FS, ACC>(src0 + sc_ * FS, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, bufA);
+    };
+    dma(s_beg);
+    float zr[ACC][3] = {};
+    float sc[ACC];
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) {
+        const int l = lrow + k * kRowsPerPass;
+        sc[k] = l < n ? a.scale[r0 + l] : 1.0f;
+    }
+    for (int i = threadIdx.x; i < per * FS; i += kThreads) {
+        const int c = s_beg * FS + i;
+        cbias[i] = (a.bias && c < a.F) ? a.bias[c] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cw2[3 * i + j] = (a.W2 && c < a.F) ? a.W2[(long)c * 3 + j] : 0.f;
+    }
+    load_table<FS, W>(a.b, r0, n, bufA, bufB, nb);
+
+    float4 y[ACC];
+    for (int s = s_beg; s < s_end; ++s) {
+        dma_wait();
+        __syncthreads();  // W1 tile of slice s landed; readers of the previous T0 tile are done
+        // gather #1: T0 tile
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n) {
+                float4 t = gather_row<FS, W, HAS_VAL, true>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+            }
+        }
+        __syncthreads();
+        dma(s + 1);  // buffer A is free: next W1 tile streams in during gather #2
+        if (s > s_beg) {  // stores of the previous slice
+            const int c = (s - 1) * FS + 4 * q;
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n && c < a.F)
+                    *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)(s - 1) * a.y_ss + 4 * q) = y[k];
+            }
+        }
+        // gather #2: H tile rows + fused W2
+        const int cl = (s - s_beg) * FS + 4 * q;
+        const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = min(lrow + k * kRowsPerPass, n - 1);
+            const float4 acc = gather_row<FS, W, false, true>(bufB, nb, nullptr, l, q);
+            y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
+            y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
+            if (a.relu) {
+                y[k].x = y[k].x > 0.f ? y[k].x : 0.f; y[k].y = y[k].y > 0.f ? y[k].y : 0.f;
+                y[k].z = y[k].z > 0.f ? y[k].z : 0.f; y[k].w = y[k].w > 0.f ? y[k].w : 0.f;
+            }
+            if (s * FS + 4 * q >= a.F) y[k] = gmc::f4_zero();  // pad columns may hold anything
+            const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
+            const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
+            const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+            zr[k][0] += y[k].x * wa.x + y[k].y * wa.w + y[k].z * wb.z + y[k].w * wc.y;
+            zr[k][1] += y[k].x * wa.y + y[k].y * wb.x + y[k].z * wb.w + y[k].w * wc.z;
+            zr[k][2] += y[k].x * wa.z + y[k].y * wb.y + y[k].z * wc.x + y[k].w * wc.w;
+        }
+    }
+    {   // stores of the last slice
+        const int c = (s_end - 1) * FS + 4 * q;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n && c < a.F)
+                *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)(s_end - 1) * a.y_ss + 4 * q) = y[k];
+        }
+    }
+    if (a.Zpart) {
+        float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            float z0 = zr[k][0], z1 = zr[k][1], z2 = zr[k][2];
+#pragma unroll
+            for (int o = Q / 2; o > 0; o >>= 1) {
+                z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); z2 += __shfl_xor(z2, o, GMC_WAVE);
+            }
+            const int l = lrow + k * kRowsPerPass;
+            if (q == 0 && l < n) {
+                zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = z2 * sc[k];
+            }
         }
     }
 }
@@ -444,6 +582,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     };
     fetch(g0);
     commit_table(a.b.goff[g0 + 1] - a.b.goff[g0]);
+    dma_wait();
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
         const int r0 = a.b.goff[g];
@@ -497,6 +636,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
         }
+        dma_wait();
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
         if (g + 1 < g1) commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
         __syncthreads();
@@ -655,6 +795,43 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     if (acc <= 8) return hv ? launch(bwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
                             : launch(bwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
     return GMC_ERR_UNSUPPORTED;
+}
+
+template <int FS, int W>
+int launch_fwd1(const TileArgs &a, size_t lds, hipStream_t st) {
+    constexpr int rows_per_pass = kThreads / (FS / 4);
+    const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
+    const int grid = a.b.B * a.groups;
+    if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
+    if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    return GMC_ERR_UNSUPPORTED;
+}
+
+// fused layer-1 forward: H (slab layout) = relu(dinv o (A @ (dinv o (A_val @ W1[:n]))) + b1) and
+// Zpart[group][r][:] = dinv[r] * (H[r, group's columns] @ W2[group's rows])
+int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, const float *W2, float *H,
+                        float *Zpart, int F, hipStream_t st) {
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    if (b->B == 0) return GMC_OK;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    TileArgs a{*b, W1, (long)F, (long)fs, 1, b->ell_vals != nullptr, b->dinv, b1, 1, H, (long)fs, (long)b->R * fs,
+               F, (F + fs - 1) / fs, gmc_lds_groups(b, F), W2, Zpart, 0};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    GmcProbeScope probe(GMC_K_FWD1_FUSED, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_fwd1<64, 8>(a, lds, st);
+            case 32: return launch_fwd1<32, 8>(a, lds, st);
+            default: return launch_fwd1<16, 8>(a, lds, st);
+        }
+    }
+    switch (fs) {
+        case 64: return launch_fwd1<64, 16>(a, lds, st);
+        case 32: return launch_fwd1<32, 16>(a, lds, st);
+        default: return launch_fwd1<16, 16>(a, lds, st);
+    }
 }
 
 // fused layer-1 backward over the slab-layout H: dW1 partials [chunks][n_max][F] and column

@@ -103,6 +103,11 @@ enum {
  * of this library is bracketed by hipEventRecord on the stream it is launched on.
  * gmc_probe_end synchronises on the last event and returns the number of launches seen,
  * writing up to `max` (tag, milliseconds) pairs (host pointers). */
+/* Kernel-sequence option: 1 (default) = fused layer kernels (T0 / Gs / U never leave LDS);
+ * 0 = one kernel per operation (stand-alone SpMM, hidden backward, dW1).  Same results to
+ * rounding.  Returns the previous setting.  Workspace sizes do not depend on it. */
+int gmc_set_fuse(int on);
+
 int gmc_probe_begin(int32_t capacity);
 int gmc_probe_end(int32_t *tags, float *ms, int32_t max);
 
