@@ -315,17 +315,22 @@ class FusedTrainer:
         """One pass over the dataset; returns the cumulative loss (one host sync)."""
         self.prepare(dataset)
         eng, cfg = self.eng, self.config
-        self._loss_slots.zero_()
         for i, batch in enumerate(self._batches):
             eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
             if self.world > 1:
                 eng.allreduce_grad()
             eng.adam_step(cfg.learning_rate)
-        per_step = self._loss_slots.sum(dim=1)
         if self.world > 1:
+            per_step = self._loss_slots.sum(dim=1)
             dist.all_reduce(per_step, op=dist.ReduceOp.SUM)
-        # the reference adds one float per optimizer step (loss.item(), :388)
-        return float(sum(per_step.cpu().tolist()))
+            return float(sum(per_step.cpu().tolist()))
+        # one device->host copy per epoch; the reference adds one float per optimizer step
+        # (loss.item(), :388), each the sum of that step's per-graph losses
+        host = self._loss_slots.cpu().numpy()
+        total = 0.0
+        for i, batch in enumerate(self._batches):
+            total += float(host[i, :batch.B].sum(dtype=np.float32))
+        return total
 
     def sync_optimizer_state(self) -> None:
         """Expose step / exp_avg / exp_avg_sq of the fused Adam through ``optimizer.state``."""
