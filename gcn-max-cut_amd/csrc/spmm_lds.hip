@@ -72,6 +72,25 @@ __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
     }
 }
 
+// block -> (graph, group), group-major inside each XCD: every graph of the XCD runs group 0,
+// then group 1, ...  Used when the big shared operand is per GROUP (the W1 column slices of
+// the fused forward: 256 KB re-read by all graphs stays hot in the XCD's L2) rather than per
+// graph.
+__device__ __forceinline__ void tile_of_group_major(int b, int B, int S, int &g, int &s) {
+    const int per_xcd = B / 8;
+    const int full = per_xcd * 8 * S;
+    if (b < full) {
+        const int xcd = b & 7, j = b >> 3;
+        s = j / per_xcd;
+        g = (j % per_xcd) * 8 + xcd;
+    } else {
+        const int t = b - full;
+        const int rem = B - per_xcd * 8;
+        g = per_xcd * 8 + t % rem;
+        s = t / rem;
+    }
+}
+
 // LDS: two tiles [(n_max + 1)][FS] floats (row n = zeros, the padding target), then the
 // neighbour table [n_max][W] of 16-bit ids.
 __host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + 1) * FS; }
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
     int g, grp;
-    tile_of((int)blockIdx.x, a.b.B, a.groups, g, grp);
+    tile_of_group_major((int)blockIdx.x, a.b.B, a.groups, g, grp);
     const int r0 = a.b.goff[g];
     const int n = a.b.goff[g + 1] - r0;
     const int per = (a.slices + a.groups - 1) / a.groups;
