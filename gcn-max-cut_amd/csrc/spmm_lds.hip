@@ -467,7 +467,6 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
             }
         }
         __syncthreads();
-        dma(s + 1);  // buffer A is free: next W1 tile streams in during gather #2
         if (s > s_beg) {  // stores of the previous slice
             const int c = (s - 1) * FS + 4 * q;
 #pragma unroll
@@ -477,6 +476,8 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                     *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)(s - 1) * a.y_ss + 4 * q) = y[k];
             }
         }
+        dma(s + 1);  // buffer A is free: next W1 tile streams in during gather #2 (issued after the
+                     // stores so that no compiler-inserted wait between them can drain it)
         // gather #2: H tile rows + fused W2
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
