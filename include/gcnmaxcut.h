@@ -96,7 +96,8 @@ enum {
     GMC_K_DENSE_MFMA = 10,
     GMC_K_BWD1_FUSED = 11, /* hidden backward + conv1 backward aggregation + dW1, one pass over H */
     GMC_K_FWD1_FUSED = 12, /* W1 gather + layer-1 aggregation (+ fused H@W2), one kernel */
-    GMC_K_COUNT = 13
+    GMC_K_DECODE = 13,     /* post-processing sampler + cut count */
+    GMC_K_COUNT = 14
 };
 
 /* Timing probe for bench.py: between gmc_probe_begin and gmc_probe_end every kernel launch
@@ -173,6 +174,21 @@ int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C, v
 int gmc_backward_from_gp(const gmc_batch *batch, const gmc_model *model, void *workspace,
                          size_t workspace_bytes, const float *P, const float *GP, float *grad,
                          gmc_stream_t stream);
+
+/* ---- decode / post-processing (the caller of the path in BASELINE configs[4]) -------- */
+
+/* Random-sampling post-processing of Testing/TestingNeuralNetwork.py:18-98 for every graph of
+ * the batch: `iters` samples of the node probabilities P [R,3] (nodes 0,1,2 of each graph fixed
+ * to classes 0,1,2; node l >= 3 takes the first class whose running float32 sum exceeds its
+ * uniform draw, last class as fallback), cut value of each sample, strictly-best sample kept.
+ * uniforms: device doubles, for graph g `iters` x (n_g - 3) values starting at uoff[g] (device
+ * int64 [B+1]) in the reference's draw order (iteration-major, node-minor).
+ * Outputs (device): assign_all [iters][R] int8, cut_all [B][iters], best_assign [R] int32,
+ * best_cut [B], best_iter [B]. */
+int gmc_decode_sample_f32(const gmc_batch *batch, const float *P, const double *uniforms,
+                          const int64_t *uoff, int32_t iters, int8_t *assign_all, float *cut_all,
+                          int32_t *best_assign, float *best_cut, int32_t *best_iter,
+                          gmc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -341,3 +341,50 @@ def test_checkpoint_round_trip(pkg, tmp_path, monkeypatch):
     assert tuple(inputs.shape) == (1000, 1000) and cfg2.hidden_dim == 16
     a, b = T.evaluate_model(net, ds, cfg2), T.evaluate_model(net2, ds, cfg2)
     assert a == b
+
+
+def test_decode_and_post_processing_match_reference_goldens(pkg):
+    """gmc_decode_sample_f32 against vectors recorded from the reference's own
+    TestingNeuralNetwork functions (tests/golden/decode.json) - exact."""
+    import json, os
+    from gcn_max_cut_amd.Testing import TestingNeuralNetwork as TN
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "decode.json")))["cases"]
+    for case in cases:
+        g = R.regular_graph(case["n"], case["d"], case["seed"])
+        probs = torch.tensor(case["probs"], dtype=torch.float32)
+        assert TN.simple_partition_assignment(probs) == case["simple_assignment"]
+        assert TN.calculate_cut_value(case["simple_assignment"], g) == case["simple_cut"]
+        np.random.seed(case["np_seed"])
+        best, cut = TN.post_processing_optimization(probs, g, iterations=case["post_iterations"])
+        assert cut == case["post_cut"] and best == case["post_assignment"]
+        # first two samples individually (iterations=1 consumes exactly one sample's draws)
+        np.random.seed(case["np_seed"])
+        s0, c0 = TN.post_processing_optimization(probs, g, iterations=1)
+        s1, _ = TN.post_processing_optimization(probs, g, iterations=1)
+        assert s0 == case["sample0"] and s1 == case["sample1"] and c0 == case["sample0_cut"]
+
+
+def test_inference_harness_matches_oracle_post_processing(pkg):
+    """test_multiple_graphs (config 5 shape: mixed sizes) == oracle decode with the same RNG."""
+    from gcn_max_cut_amd.Testing import TestingNeuralNetwork as TN
+    T, cfg, net, *_rest, params = model_and_params(pkg, 64)
+    specs = [(50, 6, 50001), (100, 7, 100001), (200, 8, 200001), (300, 6, 300001), (500, 7, 500001)]
+    ds = util.product_dataset(specs)
+    np.random.seed(0)
+    results, by_size = TN.test_multiple_graphs(net, ds, [50, 100, 200, 300, 500], post_processing_iterations=20, verbose=False)
+    assert len(results) == 5 and all(r["success"] for r in results)
+    np.random.seed(0)
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    for r, (g, a_pad, nx_g, _t) in zip(results, ds.values()):
+        P = torch.from_numpy(r["node_probabilities"])
+        assert r["simple_assignment"] == R.partition_of(P).tolist()
+        assert r["simple_cut"] == R.cut_value(r["simple_assignment"], nx_g)
+        best, cut = R.post_process(r["node_probabilities"], nx_g, 20, np.random.rand)
+        assert r["post_cut"] == cut and r["post_assignment"] == best
+        assert r["improvement"] == cut - r["simple_cut"]
+    assert by_size[500]["post_processed"]["cut_values"] == [results[4]["post_cut"]]
+    # batched throughput form gives the same numbers
+    np.random.seed(0)
+    fast = TN.decode_dataset(net, ds, 20)
+    for r, f in zip(results, fast):
+        assert (f["simple_cut"], f["post_cut"], f["post_assignment"]) == (r["simple_cut"], r["post_cut"], r["post_assignment"])
