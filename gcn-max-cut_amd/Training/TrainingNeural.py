@@ -286,6 +286,8 @@ class FusedTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._plan_key = None
+        self._graph = None          # hipGraph of one whole epoch (single GPU, several steps per epoch)
+        self._graph_steps = 0
         self._batches: List[GraphBatch] = []
         self._loss_slots: Optional[torch.Tensor] = None
         self._out = None
@@ -310,16 +312,20 @@ class FusedTrainer:
                      torch.empty(rmax, dtype=torch.int32, device=dev))
         self._loss_slots = torch.zeros((len(self._batches), max(bmax, 1)), dtype=torch.float32, device=dev)
         self._plan_key = key
+        self._graph = None
 
     def epoch(self, dataset: Dict) -> float:
         """One pass over the dataset; returns the cumulative loss (one host sync)."""
         self.prepare(dataset)
         eng, cfg = self.eng, self.config
-        for i, batch in enumerate(self._batches):
-            eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
-            if self.world > 1:
-                eng.allreduce_grad()
-            eng.adam_step(cfg.learning_rate)
+        if self._use_graph():
+            self._replay_epoch()
+        else:
+            for i, batch in enumerate(self._batches):
+                eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+                if self.world > 1:
+                    eng.allreduce_grad()
+                eng.adam_step(cfg.learning_rate)
         if self.world > 1:
             per_step = self._loss_slots.sum(dim=1)
             dist.all_reduce(per_step, op=dist.ReduceOp.SUM)
@@ -331,6 +337,33 @@ class FusedTrainer:
         for i, batch in enumerate(self._batches):
             total += float(host[i, :batch.B].sum(dtype=np.float32))
         return total
+
+    def _use_graph(self) -> bool:
+        """Launch-bound schedules (the reference's one Adam step per graph: hundreds of ~10 us
+        kernels per epoch) are captured once into a hipGraph and replayed per epoch."""
+        return (self.world == 1 and len(self._batches) >= 2 and hasattr(self.eng, "adam_step_dev")
+                and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
+
+    def _enqueue_epoch(self) -> None:
+        eng, cfg = self.eng, self.config
+        for i, batch in enumerate(self._batches):
+            eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+            eng.adam_step_dev(cfg.learning_rate)
+
+    def _replay_epoch(self) -> None:
+        eng = self.eng
+        eng.step_dev.fill_(eng.step_count)
+        if self._graph is None:
+            self._enqueue_epoch()                 # eager epoch: sizes the workspace, warms the kernels
+            graph = torch.cuda.CUDAGraph()
+            before = eng.step_count
+            with torch.cuda.graph(graph):
+                self._enqueue_epoch()
+            eng.step_count = before               # capture enqueued nothing
+            self._graph, self._graph_steps = graph, len(self._batches)
+            return
+        self._graph.replay()
+        eng.step_count += self._graph_steps
 
     def sync_optimizer_state(self) -> None:
         """Expose step / exp_avg / exp_avg_sq of the fused Adam through ``optimizer.state``."""

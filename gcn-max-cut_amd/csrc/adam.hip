@@ -42,7 +42,75 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
     }
 }
 
+// Graph-replayable form: the step number lives in device memory (a captured launch cannot take
+// a new scalar per replay).  Every block derives the bias corrections from *step_counter + 1 in
+// double, exactly as the host does for gmc_adam_f32; adam_tick_kernel then advances the counter.
+struct AdamDevArgs {
+    float *p;
+    const float *g;
+    float *m;
+    float *v;
+    long n;
+    double lr, beta1, beta2;
+    float eps;
+    const int *step_counter;
+};
+
+__global__ __launch_bounds__(256) void adam_devstep_kernel(AdamDevArgs d) {
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)(*d.step_counter + 1);
+        const double bc1 = 1.0 - pow(d.beta1, t), bc2 = 1.0 - pow(d.beta2, t);
+        sh[0] = (float)(d.lr / bc1);
+        sh[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
+    const AdamArgs a{d.p, d.g, d.m, d.v, d.n, (float)(1.0 - d.beta1), (float)d.beta2, (float)(1.0 - d.beta2),
+                     sh[0], sh[1], d.eps};
+    const long n4 = a.n >> 2;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<float4 *>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4 *>(a.g)[i];
+        float4 m = reinterpret_cast<float4 *>(a.m)[i];
+        float4 v = reinterpret_cast<float4 *>(a.v)[i];
+        adam1(p.x, g.x, m.x, v.x, a); adam1(p.y, g.y, m.y, v.y, a);
+        adam1(p.z, g.z, m.z, v.z, a); adam1(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4 *>(a.p)[i] = p;
+        reinterpret_cast<float4 *>(a.m)[i] = m;
+        reinterpret_cast<float4 *>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0) {
+        const long i = (n4 << 2) + threadIdx.x;
+        if (i < a.n) adam1(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    }
+}
+
+__global__ void adam_tick_kernel(int *step_counter) { *step_counter += 1; }
+
 }  // namespace
+
+extern "C" int gmc_adam_devstep_f32(float *param, const float *grad, float *m, float *v, int64_t count,
+                                    double lr, double beta1, double beta2, double eps, int32_t *step_counter,
+                                    gmc_stream_t stream) {
+    if (!param || !grad || !m || !v || !step_counter) return GMC_ERR_NULL;
+    if (count < 0) return GMC_ERR_SHAPE;
+    if (!gmc_aligned16(param) || !gmc_aligned16(grad) || !gmc_aligned16(m) || !gmc_aligned16(v))
+        return GMC_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (count > 0) {
+        AdamDevArgs d{param, grad, m, v, (long)count, lr, beta1, beta2, (float)eps, step_counter};
+        long blocks = ((count >> 2) + 255) / 256;
+        if (blocks < 1) blocks = 1;
+        if (blocks > 2048) blocks = 2048;
+        GmcProbeScope probe(GMC_K_ADAM, st);
+        hipLaunchKernelGGL(adam_devstep_kernel, dim3((int)blocks), dim3(256), 0, st, d);
+        GMC_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
 
 extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count,
                             double lr, double beta1, double beta2, double eps, int32_t step,

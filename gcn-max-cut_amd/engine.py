@@ -46,6 +46,7 @@ class FusedEngine:
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.step_count = 0
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)  # device mirror of step_count
         self._ws: Optional[torch.Tensor] = None
         self._model = hip.GmcModel()
         self._refresh_model()
@@ -139,6 +140,16 @@ class FusedEngine:
                                    hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
                                    self.step_count, hip.stream())
         hip.check(rc, "gmc_adam_f32")
+
+    def adam_step_dev(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+        """Same update with the step number read from (and advanced in) device memory, so the
+        launch can be captured into a hipGraph and replayed (``step_dev`` must equal
+        ``step_count`` on entry; both advance by one)."""
+        rc = self.lib.gmc_adam_devstep_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
+                                           hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
+                                           hip.ptr(self.step_dev), hip.stream())
+        hip.check(rc, "gmc_adam_devstep_f32")
+        self.step_count += 1
 
     def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""

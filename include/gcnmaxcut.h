@@ -149,6 +149,14 @@ int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const
 int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count, double lr,
                  double beta1, double beta2, double eps, int32_t step, gmc_stream_t stream);
 
+/* Same update with the step number kept in device memory (*step_counter = steps done so far;
+ * the call uses step_counter+1 and then increments it on the stream).  All arguments are
+ * replay-invariant, so a whole epoch of the reference's one-step-per-graph schedule
+ * (TrainingNeural.py:371-386) can be captured once into a hipGraph and replayed. */
+int gmc_adam_devstep_f32(float *param, const float *grad, float *m, float *v, int64_t count, double lr,
+                         double beta1, double beta2, double eps, int32_t *step_counter,
+                         gmc_stream_t stream);
+
 /* ---- fused entry points ------------------------------------------------------------ */
 
 /* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
