@@ -12,6 +12,7 @@ int gmc_hidden_bwd_slab_launch(const float *, const float *, const float *, cons
 int gmc_lds_slice_width(const gmc_batch *b);
 int gmc_dw1_chunks(int B, bool lds);
 int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
+bool gmc_bwd1_fits(const gmc_batch *b);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
                         hipStream_t);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
@@ -36,7 +37,7 @@ struct Workspace {
     float *T0;       // [R,ld]  (X o dinv)@W1, later Gs = dinv o Gpre
     float *H;        // [R,ld]  relu(conv1), later U = dinv o (A @ Gs)
     float *Z0;       // [zparts,R,3]
-    float *GY2;      // [R,3]
+    float *GY2;      // [R,4] = (GY2[r,0..2], dinv[r])
     float *part;     // [tiles,F,4]
     float *db2part;  // [B,3]
     float *dw1part;  // [chunks,N,F]
@@ -81,7 +82,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     w.H = take(R * cols);
     w.Z0 = take((size_t)w.zparts * R * 3);
     if (training) {
-        w.GY2 = take(R * 3);
+        w.GY2 = take(R * 4);  // (GY2[r,0..2], dinv[r]) per row: one aligned 16 B load downstream
         size_t tiles = w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R);
         if (w.fs && (size_t)gmc_dw1_chunks(b->B, true) > tiles) tiles = gmc_dw1_chunks(b->B, true);
         w.part = take(tiles * F * 4);
@@ -136,7 +137,7 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
-    if (w.fs && fuse_enabled()) {  // one pass over H: Gs and U live only in LDS
+    if (w.fs && fuse_enabled() && gmc_bwd1_fits(b)) {  // one pass over H: Gs and U live only in LDS
         const int chunks = gmc_dw1_chunks(b->B, true), per = (b->B + chunks - 1) / chunks;
         int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
         if (rc) return rc;

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
             const int c = a.b.lcol[e];
             y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2];
         }
-        a.GY2[(long)r * 3] = y0; a.GY2[(long)r * 3 + 1] = y1; a.GY2[(long)r * 3 + 2] = y2;
+        *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, a.b.dinv[r]);
     }
 }
 
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs a) {
             const int c = a.b.lcol[e];
             y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2];
         }
-        a.GY2[(long)r * 3] = y0; a.GY2[(long)r * 3 + 1] = y1; a.GY2[(long)r * 3 + 2] = y2;
+        *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, a.b.dinv[r]);
     }
 }
 

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kColThreads * kRowLanes) void hidden_bwd_kernel(Hid
     for (int r = rbeg + rl; r < rend; r += kRowLanes) {
         const float4 h = reinterpret_cast<const float4 *>(a.H + (long)r * a.ldh)[cl];
         const float d = a.dinv[r];
-        const float g0 = a.GY2[(long)r * 3], g1 = a.GY2[(long)r * 3 + 1], g2 = a.GY2[(long)r * 3 + 2];
+        const float g0 = a.GY2[(long)r * 4], g1 = a.GY2[(long)r * 4 + 1], g2 = a.GY2[(long)r * 4 + 2];
         const float hv[4] = {h.x, h.y, h.z, h.w};
         float gs[4];
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void hidden_bwd_slab_kernel(HiddenSlabArgs a) 
         const long off = slab + (long)r * FS + 4 * q;
         const float4 h = *reinterpret_cast<const float4 *>(a.H + off);
         const float d = a.dinv[r];
-        const float g0 = a.GY2[(long)r * 3], g1 = a.GY2[(long)r * 3 + 1], g2 = a.GY2[(long)r * 3 + 2];
+        const float g0 = a.GY2[(long)r * 4], g1 = a.GY2[(long)r * 4 + 1], g2 = a.GY2[(long)r * 4 + 2];
         const float hv[4] = {h.x, h.y, h.z, h.w};
         float gs[4];
 #pragma unroll

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
 struct Bwd1Args {
     gmc_batch b;
     const float *H;       // slab layout [slice][R][FS]
-    const float *GY2;     // [R][3]
+    const float *GY2;     // [R][4] = (GY2[r,0..2], dinv[r])
     const float *W2;      // [F][3]
     float *dw1part;       // [chunks][n_max][F]
     float *colpart;       // [chunks][F][4]
@@ -615,9 +615,9 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
             dv[k] = 1.f;
             if (l < n) {
                 const int r = r0 + l;
-                const float d = a.b.dinv[r];
+                const float4 rcst = *reinterpret_cast<const float4 *>(a.GY2 + (long)r * 4);  // (GY2[r,:], dinv[r])
+                const float gy0 = rcst.x, gy1 = rcst.y, gy2 = rcst.z, d = rcst.w;
                 dv[k] = d;
-                const float gy0 = a.GY2[(long)r * 3], gy1 = a.GY2[(long)r * 3 + 1], gy2 = a.GY2[(long)r * 3 + 2];
                 float4 *cell = reinterpret_cast<float4 *>(bufA) + l * Q + q;
                 const float4 h = *cell;
                 const float hv[4] = {h.x, h.y, h.z, h.w};
@@ -757,6 +757,8 @@ bool gmc_lds_fits(const gmc_batch *b) {
     const int rows_per_pass = kThreads / (fs / 4);
     return (b->n_max + rows_per_pass - 1) / rows_per_pass <= 8;
 }
+
+bool gmc_bwd1_fits(const gmc_batch *b) { return gmc_lds_fits(b); }
 
 // slice groups (workgroups) per graph == number of Zpart partials of the fused W2 epilogue.
 // Fixed per model shape (independent of the batch), so a graph's result is bitwise the same

@@ -136,7 +136,8 @@ int gmc_dense_hw2_f32(const float *H, int64_t ldh, const float *dinv, const floa
  * rows 0,1,2 forced to e0,e1,e2 and S = row-argmax, first max wins (:87-106);
  * loss[g] = -C * cut(S) (:154-176,:291-309).  When GY2 != NULL also the start of
  * loss.backward(): GP = C*A_val@onehot(S), softmax backward, db2part[g,:] = colsum(GZ),
- * GY2 = A @ (dinv*GZ).  P [R,3], S [R], loss [B], db2part [B,3], GY2 [R,3].
+ * GY2 = A @ (dinv*GZ).  P [R,3], S [R], loss [B], db2part [B,3], GY2 [R,4] = (GY2[r,0..2], dinv[r])
+ * (16-byte rows so the backward kernels fetch a row's constants with one aligned load).
  * Z0 is [z_parts][R][3]: partial products of the LDS-tiled layer-1 kernel (one per column
  * slice group), folded here in ascending order; z_parts = 1 for a plain [R,3] Z0. */
 int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2, float C,
