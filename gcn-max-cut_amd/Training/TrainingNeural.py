@@ -131,12 +131,46 @@ class GCNSoftmax(nn.Module):
             raise NotImplementedError("dropout > 0 is not implemented on the fused HIP path "
                                       "(every reference configuration uses dropout=0.0)")
         eng = self.engine()
-        batch = graph_batch_of(g, inputs, eng.device)
+        try:
+            batch = graph_batch_of(g, inputs, eng.device)
+        except NotImplementedError:
+            return self._forward_dense_features(g, inputs)
         params = [dict(self.named_parameters())[k] for k in PARAM_ORDER]
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _GCNForward.apply(self, batch, *params)
         P, _, _ = eng.forward(batch)
         return P
+
+    def _forward_dense_features(self, g, inputs):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "gradients are implemented for the reference's usage net(g, padded_adjacency) "
+                "(TrainingNeural.py:373); call under torch.no_grad() for arbitrary features")
+        return _dense_forward(self, g, inputs)
+
+
+def _dense_forward(net: "GCNSoftmax", g: GraphHandle, inputs: torch.Tensor) -> torch.Tensor:
+    """``net(g, X)`` for features that are NOT the padded adjacency (non-zeros off the edges):
+    the layer-1 feature transform is then a genuine dense GEMM (rocBLAS through torch.matmul,
+    the "plain library GEMM" case), everything after it runs in the HIP kernels.  Inference
+    only - no gradient is defined on this path."""
+    eng = net.engine()
+    lib, p = hip.load(), hip.ptr
+    batch = GraphBatch([g], [None], eng.device)
+    v = eng.views()
+    X = inputs.detach().to(eng.device, torch.float32)
+    if X.shape != (g.n, eng.N):
+        raise ValueError(f"features must be [{g.n}, {eng.N}], got {tuple(X.shape)}")
+    T0 = ((X * batch.dinv[:, None]) @ v["conv1.weight"]).contiguous()
+    F_ = eng.F
+    H = torch.empty((g.n, F_), dtype=torch.float32, device=eng.device)
+    Z0 = torch.empty((g.n, 3), dtype=torch.float32, device=eng.device)
+    P = torch.empty((g.n, 3), dtype=torch.float32, device=eng.device)
+    hip.check(lib.gmc_spmm_f32(p(batch.rowptr), p(batch.gcol), None, p(batch.dinv), p(T0), F_, p(v["conv1.bias"]), 1,
+                               p(H), F_, g.n, F_, 0, p(v["conv2.weight"]), p(Z0), hip.stream()), "gmc_spmm_f32")
+    hip.check(lib.gmc_head_f32(batch.ref(), p(Z0), 1, p(v["conv2.bias"]), 1.0, p(P), None, None, None, None,
+                               hip.stream()), "gmc_head_f32")
+    return P
 
 
 def graph_batch_of(g: GraphHandle, inputs, device) -> GraphBatch:

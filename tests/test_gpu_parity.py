@@ -388,3 +388,21 @@ def test_inference_harness_matches_oracle_post_processing(pkg):
     fast = TN.decode_dataset(net, ds, 20)
     for r, f in zip(results, fast):
         assert (f["simple_cut"], f["post_cut"], f["post_assignment"]) == (r["simple_cut"], r["post_cut"], r["post_assignment"])
+
+
+def test_forward_with_arbitrary_dense_features(pkg):
+    """net(g, X) with X that is not the adjacency: dense layer-1 GEMM + HIP kernels (inference)."""
+    T, cfg, net, *_rest, params = model_and_params(pkg, 32)
+    ds = util.product_dataset([(60, 5, 77)])
+    (g, a_pad, nx_g, _t), = ds.values()
+    torch.manual_seed(1)
+    X = torch.randn(60, 1000)
+    net.eval()
+    with torch.no_grad():
+        P = net(g, X.cuda()).cpu()
+    tp = {k: torch.from_numpy(v) for k, v in params.items()}
+    ref = R.forward(tp, R.graph_from_networkx(nx_g), X)
+    assert float((P - ref).abs().max()) < PROB_TOL
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(g, X.cuda())
