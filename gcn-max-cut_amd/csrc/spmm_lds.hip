@@ -29,6 +29,35 @@
 #include "gmc_common.h"
 #include <stdlib.h>
 
+// Diagnostic build only (-DGMC_STAMP, `make stamp`): wave 0 of every workgroup accumulates the
+// shader-clock cycles it spends in each phase of the fused kernels' tile loop into g_stamps
+// (never read by any kernel); gmc_debug_read_stamps copies them out.  The production library
+// contains none of this.
+#ifdef GMC_STAMP
+__device__ unsigned long long g_stamps[4096 * 16];
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {}
+#define STAMP(i)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += st_now - st_last;                               \
+        st_last = st_now;                                            \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#define STAMP_FLUSH                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                     \
+            for (int i = 0; i < 12; ++i) g_stamps[blockIdx.x * 16 + i] = st_acc[i];    \
+    } while (0)
+extern "C" int gmc_debug_read_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 namespace {
 
 constexpr int kThreads = 1024;
@@ -453,9 +482,13 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     load_table<FS, W>(a.b, r0, n, bufA, bufB, nb);
 
     float4 y[ACC];
+    STAMP_DECL;
     for (int s = s_beg; s < s_end; ++s) {
+        STAMP(0);  // loop overhead / previous tail
         dma_wait();
+        STAMP(1);  // DMA wait
         __syncthreads();  // W1 tile of slice s landed; readers of the previous T0 tile are done
+        STAMP(2);  // barrier 1
         // gather #1: T0 tile
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -466,7 +499,9 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
             }
         }
+        STAMP(3);  // gather 1
         __syncthreads();
+        STAMP(4);  // barrier 2
         if (s > s_beg) {  // stores of the previous slice
             const int c = (s - 1) * FS + 4 * q;
 #pragma unroll
@@ -478,6 +513,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
         }
         dma(s + 1);  // buffer A is free: next W1 tile streams in during gather #2 (issued after the
                      // stores so that no compiler-inserted wait between them can drain it)
+        STAMP(5);  // stores + DMA issue
         // gather #2: H tile rows + fused W2
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
@@ -499,7 +535,9 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
             zr[k][1] += y[k].x * wa.y + y[k].y * wb.x + y[k].z * wb.w + y[k].w * wc.z;
             zr[k][2] += y[k].x * wa.z + y[k].y * wb.y + y[k].z * wc.x + y[k].w * wc.w;
         }
+        STAMP(6);  // gather 2
     }
+    STAMP_FLUSH;
     {   // stores of the last slice
         const int c = (s_end - 1) * FS + 4 * q;
 #pragma unroll
@@ -604,10 +642,12 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     commit_table(a.b.goff[g0 + 1] - a.b.goff[g0]);
     dma_wait();
     __syncthreads();
+    STAMP_DECL;
     for (int g = g0; g < g1; ++g) {
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
         float dv[ACC];
+        STAMP(0);
         // (1) H -> Gs in place + column partials
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -636,7 +676,9 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
                 *cell = make_float4(gs[0], gs[1], gs[2], gs[3]);
             }
         }
+        STAMP(1);  // transform
         __syncthreads();
+        STAMP(2);  // barrier A
         // (2) U tile = dinv o (A @ Gs)
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -647,20 +689,29 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
         }
+        STAMP(3);  // gather 1
         __syncthreads();
+        STAMP(4);  // barrier B
         // (3) next graph's H tile streams into bufA while (4) gathers from bufB
         if (g + 1 < g1) fetch(g + 1);
+        STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
         }
+        STAMP(6);  // gather 2
         dma_wait();
+        STAMP(7);  // DMA wait
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
+        STAMP(8);  // barrier C
         if (g + 1 < g1) commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
+        STAMP(9);  // commit table
         __syncthreads();
+        STAMP(10); // barrier D
     }
+    STAMP_FLUSH;
     if (col_on) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {

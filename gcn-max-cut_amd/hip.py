@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libgcnmaxcut_hip.so")
+LIB_PATH = os.environ.get("GCN_MAXCUT_LIB") or os.path.join(_PKG, "lib", "libgcnmaxcut_hip.so")
 
 # every symbol include/gcnmaxcut.h declares (tests check the .so exports all of them)
 SYMBOLS = (

@@ -1,0 +1,27 @@
+import sys, os, json; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["GCN_MAXCUT_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gcn-max-cut_amd", "lib", "libgcnmaxcut_hip_stamp.so")
+import ctypes as C, numpy as np, torch, networkx as nx
+import gcn_max_cut_amd as pkg
+from gcn_max_cut_amd.Training import TrainingNeural as T
+B, n, d, F = 160, 1000, 7, 500
+hs = [pkg.from_networkx(nx.random_regular_graph(d, n, seed=3000 + i)) for i in range(B)]
+batch = pkg.GraphBatch(hs, None)
+net, _, _ = T.setup_model_and_optimizer(T.TrainingConfig(n_nodes=1000, hidden_dim=F))
+eng = net.engine(); lib = pkg.hip.load()
+names = {"fwd": ["loop", "dma_wait", "barrier1", "gather1", "barrier2", "stores+dma", "gather2"],
+         "bwd": ["loop", "transform", "barrierA", "gather1", "barrierB", "fetch", "gather2", "dma_wait", "barrierC", "commit", "barrierD"]}
+def read(nblk):
+    buf = (C.c_ulonglong * (nblk * 16))()
+    rc = lib.gmc_debug_read_stamps(buf, nblk * 16); assert rc == 0
+    return np.frombuffer(buf, dtype=np.uint64).reshape(nblk, 16).astype(np.float64)
+for _ in range(3): eng.train_fwd_bwd(batch)
+torch.cuda.synchronize()
+# forward only -> stamps of fwd1 (grid 1280)
+eng.forward(batch); torch.cuda.synchronize()
+a = read(1280)
+tot = a[:, :7].sum(1).mean()
+print("fwd1 cycles per WG %.0f" % tot, {k: round(100 * a[:, i].mean() / tot, 1) for i, k in enumerate(names["fwd"])})
+eng.train_fwd_bwd(batch); torch.cuda.synchronize()
+b = read(512)
+tot = b[:, :11].sum(1).mean()
+print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})
