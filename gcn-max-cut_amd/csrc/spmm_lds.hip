@@ -120,9 +120,10 @@ __device__ __forceinline__ void tile_of_group_major(int b, int B, int S, int &g,
     }
 }
 
-// LDS: two tiles [(n_max + 1)][FS] floats (row n = zeros, the padding target), then the
-// neighbour table [n_max][W] of 16-bit ids.
-__host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + 1) * FS; }
+// LDS: two tiles [(n_max + 4)][FS] floats (rows n..n+3 = zeros: the padding targets, one per
+// bank quarter, see ell_arrange.hip), then the neighbour table [n_max][W] of 16-bit ids.
+constexpr int kPadRows = 4;
+__host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + kPadRows) * FS; }
 constexpr int kMaxSlicesPerWg = 8;
 size_t lds_bytes(int n_max, int W, int FS) {
     // + the larger of: bias and W2 rows of up to kMaxSlicesPerWg slices (spmm: 8 * FS * 16 B) and
@@ -165,7 +166,7 @@ __device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, fl
     const uint4 *src = reinterpret_cast<const uint4 *>(b.ell + (long)r0 * W);
     const int total = n * (W / 8);
     for (int i = threadIdx.x; i < total; i += kThreads) reinterpret_cast<uint4 *>(nb)[i] = src[i];
-    if (threadIdx.x < FS) {
+    if (threadIdx.x < kPadRows * FS) {
         tile0[(long)n * FS + threadIdx.x] = 0.f;
         tile1[(long)n * FS + threadIdx.x] = 0.f;
     }
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
     {
         const int n = a.b.goff[g0 + 1] - a.b.goff[g0];
         commit_table(n);
-        if (threadIdx.x < FS) lds[n * FS + threadIdx.x] = 0.f;
+        if (threadIdx.x < kPadRows * FS) lds[n * FS + threadIdx.x] = 0.f;
     }
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
         }
         if (g + 1 < g1) {
             const int n1 = a.b.goff[g + 2] - a.b.goff[g + 1];
-            if (threadIdx.x < FS) lds[(cur ^ 1) * TF + n1 * FS + threadIdx.x] = 0.f;
+            if (threadIdx.x < kPadRows * FS) lds[(cur ^ 1) * TF + n1 * FS + threadIdx.x] = 0.f;
             __syncthreads();  // everyone is done with graph g's table
             commit_table(n1);
         }
@@ -633,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
             const int i = threadIdx.x + k * kThreads;
             if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
         }
-        if (threadIdx.x < FS) {
+        if (threadIdx.x < kPadRows * FS) {
             bufA[n * FS + threadIdx.x] = 0.f;
             bufB[n * FS + threadIdx.x] = 0.f;
         }

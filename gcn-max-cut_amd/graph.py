@@ -189,6 +189,16 @@ class BatchArrays:
             if vals is not None:
                 ell_vals = np.zeros((R, W), np.float32)
                 ell_vals[rows, slot] = vals
+            # LDS-bank-aware slot order (host routine of the library; plain CSR order otherwise)
+            try:
+                lib = hip.load()
+            except hip.HipExtensionError:
+                lib = None
+            if lib is not None:
+                ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+                go32 = goff.astype(np.int32)
+                rc = lib.gmc_ell_arrange_host(B, ptr(go32), ptr(rowptr), ptr(lcol), ptr(vals), W, ptr(ell), ptr(ell_vals))
+                hip.check(rc, "gmc_ell_arrange_host")
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
         self.nnz_max = int(nnzs.max()) if B else 0

@@ -63,8 +63,8 @@ typedef struct gmc_batch {
     const float *vals;     /* [nnz] edge weight = X[u,v], or NULL when all ones */
     const float *dinv;     /* [R] clamp(degree,1)^-1/2  (in == out degree: undirected) */
     /* Optional ELL copy of the same structure for the LDS-tiled kernels (NULL: row kernels
-     * only): W = ell_width slots per row (8 or 16, >= max degree), local neighbour ids in
-     * CSR order padded with n_g (the id of an all-zero row), weights padded with 0. */
+     * only): W = ell_width slots per row (8 or 16, >= max degree), local neighbour ids in the
+     * order gmc_ell_arrange_host chose, padded with n_g..n_g+3 (all-zero tile rows), weights 0. */
     const uint16_t *ell;   /* [R][W] */
     const float *ell_vals; /* [R][W] or NULL when all ones */
     int32_t ell_width;
@@ -80,6 +80,14 @@ typedef struct gmc_model {
 
 int gmc_version(void);
 const char *gmc_error_string(int code);
+
+/* HOST helper (all pointers are host pointers): fills the ELL neighbour table of a batch from
+ * its CSR.  Inside each group of four rows that share an LDS cycle of the tiled kernels the
+ * neighbours are ordered over the W slots so that a slot's four fetches fall into different LDS
+ * bank quarters where possible; padding entries are n_g .. n_g+3 (four all-zero tile rows).
+ * The slot order is the summation order of the LDS-tiled kernels (fixed per batch). */
+int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_t *rowptr, const int32_t *lcol,
+                         const float *vals, int32_t W, uint16_t *ell, float *ell_vals);
 
 /* Kernel tags reported by the timing probe (one per launch of the fused step). */
 enum {
