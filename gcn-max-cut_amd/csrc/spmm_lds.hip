@@ -173,30 +173,11 @@ __device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, fl
 }
 
 // sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
-// LEAN: only 4 neighbour rows in flight (register-tight callers); same summation order.
-template <int FS, int W, bool HAS_VAL, bool LEAN = false>
+template <int FS, int W, bool HAS_VAL>
 __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
                                              int l, int q) {
     constexpr int Q = FS / 4;
     float4 acc = gmc::f4_zero();
-    if (LEAN && !HAS_VAL) {
-#pragma unroll
-        for (int blk = 0; blk < W / 8; ++blk) {
-            const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
-            const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
-                                    ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float4 x[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[4 * h + u] * Q + q];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) gmc::f4_add(acc, x[u]);
-                asm volatile("" ::: "memory");  // finish this half before the next four loads
-            }
-        }
-        return acc;
-    }
 #pragma unroll
     for (int blk = 0; blk < W / 8; ++blk) {
         const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
@@ -279,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);  // rows past the end redo row n-1 (never stored)
             float4 acc = gmc::f4_zero();
-            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL, EPI>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
             y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
             y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
             if (a.relu) {
@@ -495,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
-                float4 t = gather_row<FS, W, HAS_VAL, true>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
                 t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
             }
@@ -521,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);
-            const float4 acc = gather_row<FS, W, false, true>(bufB, nb, nullptr, l, q);
+            const float4 acc = gather_row<FS, W, false>(bufB, nb, nullptr, l, q);
             y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
             y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
             if (a.relu) {
