@@ -320,7 +320,8 @@ class FusedTrainer:
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self._plan_key = None
-        self._graph = None          # hipGraph of one whole epoch (single GPU, several steps per epoch)
+        self.allow_graph = True     # set False to force eager launches (per-kernel probing)
+        self._graph = None          # hipGraph of one whole epoch (single GPU)
         self._graph_steps = 0
         self._batches: List[GraphBatch] = []
         self._loss_slots: Optional[torch.Tensor] = None
@@ -373,9 +374,11 @@ class FusedTrainer:
         return total
 
     def _use_graph(self) -> bool:
-        """Launch-bound schedules (the reference's one Adam step per graph: hundreds of ~10 us
-        kernels per epoch) are captured once into a hipGraph and replayed per epoch."""
-        return (self.world == 1 and len(self._batches) >= 2 and hasattr(self.eng, "adam_step_dev")
+        """On one GPU an epoch's launches (the reference's one Adam step per graph: hundreds of
+        ~10 us kernels; or one batched step: six) are captured once into a hipGraph and replayed per
+        epoch, which removes the per-launch host cost."""
+        return (self.allow_graph and self.world == 1 and len(self._batches) >= 1
+                and hasattr(self.eng, "adam_step_dev")
                 and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
 
     def _enqueue_epoch(self) -> None:
