@@ -89,11 +89,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # rehearsal aid (one-GPU boxes): GCN_MAXCUT_BENCH_REHEARSE=1 puts every rank on device 0 and uses
+    # gloo, to exercise the N > 1 control flow; never set by the driver
+    rehearse = os.environ.get("GCN_MAXCUT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.mode == "sequential" and world > 1:
         raise SystemExit("sequential mode is the single-GPU reference schedule")
 
@@ -157,6 +165,24 @@ def main():
             kernels.setdefault(tag, []).append(ms)
     kmean = {k: float(np.mean(v)) for k, v in kernels.items()}
 
+    # third region (EVERY rank runs it: each step holds a collective when N > 1): the same step as
+    # one kernel per operation -> timings of the stand-alone SpMM kernel
+    spmm, k2 = [], {}
+    if args.mode == "batched" and not args.no_probe:
+        lib = pkg.hip.load()
+        prev = lib.gmc_set_fuse(0)
+        for _ in range(2):
+            trainer.epoch(dataset)
+        with pkg.hip.Probe(launches_per_step * args.steps) as p2:
+            for _ in range(args.steps):
+                trainer.epoch(dataset)
+            sync()
+        lib.gmc_set_fuse(prev)
+        trainer.allow_graph = True
+        for tag, ms in p2.records:
+            k2.setdefault(tag, []).append(ms)
+        spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in k2.get(tag, [])]
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -199,24 +225,8 @@ def main():
                           "survey_unfused_GBps": unfused_mb * 1e6 * gpg / dur / 1e9}
     out["roofline_fused"] = fused or None
 
-    # second timed region: the same step as one kernel per operation -> the stand-alone SpMM
-    spmm = []
-    if args.mode == "batched" and not args.no_probe:
-        lib = pkg.hip.load()
-        prev = lib.gmc_set_fuse(0)
-        for _ in range(2):
-            trainer.epoch(dataset)
-        with pkg.hip.Probe(launches_per_step * args.steps) as p2:
-            for _ in range(args.steps):
-                trainer.epoch(dataset)
-            torch.cuda.synchronize()
-        lib.gmc_set_fuse(prev)
-        trainer.allow_graph = True
-        k2 = {}
-        for tag, ms in p2.records:
-            k2.setdefault(tag, []).append(ms)
+    if k2:
         out["kernels_ms_unfused"] = {k: round(float(np.mean(v)), 5) for k, v in sorted(k2.items())}
-        spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in k2.get(tag, [])]
     if spmm and args.mode == "batched":
         dur = float(np.mean(spmm)) * 1e-3
         achieved = spmm_bytes / dur / 1e9

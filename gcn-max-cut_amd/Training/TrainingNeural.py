@@ -355,6 +355,9 @@ class FusedTrainer:
         eng, cfg = self.eng, self.config
         if self._use_graph():
             self._replay_epoch()
+        elif self.world == 1 and hasattr(eng, "train_step"):
+            eng.step_dev.fill_(eng.step_count)
+            self._enqueue_epoch()
         else:
             for i, batch in enumerate(self._batches):
                 eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
@@ -378,14 +381,13 @@ class FusedTrainer:
         ~10 us kernels; or one batched step: six) are captured once into a hipGraph and replayed per
         epoch, which removes the per-launch host cost."""
         return (self.allow_graph and self.world == 1 and len(self._batches) >= 1
-                and hasattr(self.eng, "adam_step_dev")
+                and hasattr(self.eng, "train_step")
                 and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
 
     def _enqueue_epoch(self) -> None:
         eng, cfg = self.eng, self.config
         for i, batch in enumerate(self._batches):
-            eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
-            eng.adam_step_dev(cfg.learning_rate)
+            eng.train_step(batch, cfg.learning_rate, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
 
     def _replay_epoch(self) -> None:
         eng = self.eng

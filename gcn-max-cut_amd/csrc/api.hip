@@ -13,6 +13,8 @@ int gmc_lds_slice_width(const gmc_batch *b);
 int gmc_dw1_chunks(int B, bool lds);
 int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
 bool gmc_bwd1_fits(const gmc_batch *b);
+int gmc_finish_launch(const float *, const float *, const float *, int, int, int, int, int, float *, float *, float *,
+                      float *, double, double, double, double, int *, hipStream_t);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
                         hipStream_t);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
@@ -132,8 +134,14 @@ int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hip
     return aggregate(b, w, w.T0, w.H, F, m->b1, 1, m->W2, w.Z0, GMC_K_AGG_FWD, st);
 }
 
+struct AdamFuse {  // optional Adam fused into the gradient fold (single GPU)
+    float *param = nullptr, *m = nullptr, *v = nullptr;
+    double lr = 0, beta1 = 0, beta2 = 0, eps = 0;
+    int *step_counter = nullptr;
+};
+
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
-                  hipStream_t st) {
+                  hipStream_t st, const AdamFuse *af = nullptr) {
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
@@ -141,10 +149,12 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
         const int chunks = gmc_dw1_chunks(b->B, true), per = (b->B + chunks - 1) / chunks;
         int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
         if (rc) return rc;
-        rc = gmc_colsum_reduce_launch(w.part, chunks, m->F, dW2, db1, w.db2part, b->B, db2, st);
-        if (rc) return rc;
-        return gmc_fold_chunks_launch(w.dw1part, dW1, m->N, b->n_max, m->F, chunks, st);
+        return gmc_finish_launch(w.dw1part, w.part, w.db2part, chunks, b->n_max, m->N, m->F, b->B, grad,
+                                 af ? af->param : nullptr, af ? af->m : nullptr, af ? af->v : nullptr,
+                                 af ? af->lr : 0, af ? af->beta1 : 0, af ? af->beta2 : 0, af ? af->eps : 0,
+                                 af ? af->step_counter : nullptr, st);
     }
+    if (af) return GMC_ERR_UNSUPPORTED;  // the fused Adam rides on the fused backward
     int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, m->W2, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
                   : gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
     if (rc) return rc;
@@ -277,6 +287,41 @@ extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model,
     rc = gmc_head_f32(batch, w.Z0, w.zparts, model->b2, C, P, S, loss, w.GY2, w.db2part, stream);
     if (rc) return rc;
     return backward_body(batch, model, w, grad, st);
+}
+
+int gmc_adam_devstep_f32(float *, const float *, float *, float *, int64_t, double, double, double, double, int32_t *,
+                         gmc_stream_t);
+
+extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, float *param, float C,
+                                  void *workspace, size_t workspace_bytes, float *P, int32_t *S, float *loss,
+                                  float *grad, float *mom, float *var, double lr, double beta1, double beta2,
+                                  double eps, int32_t *step_counter, gmc_stream_t stream) {
+    if (!param || !grad || !mom || !var || !step_counter) return GMC_ERR_NULL;
+    if (!gmc_aligned16(param) || !gmc_aligned16(mom) || !gmc_aligned16(var)) return GMC_ERR_ALIGN;
+    const long nW1 = (long)N * F;
+    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3};
+    int rc = check(batch, &model);
+    if (rc) return rc;
+    if (!P || !workspace) return GMC_ERR_NULL;
+    if (!gmc_aligned16(grad)) return GMC_ERR_ALIGN;
+    Workspace w = carve(batch, &model, 1, workspace);
+    if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t count = nW1 + F + (int64_t)F * 3 + 3;
+    const bool fused = batch->R > 0 && w.fs && fuse_enabled() && gmc_bwd1_fits(batch);
+    if (!fused) {  // general shapes: gradient, then the stand-alone Adam
+        rc = gmc_train_fwd_bwd(batch, &model, C, workspace, workspace_bytes, P, S, loss, grad, stream);
+        if (rc) return rc;
+        return gmc_adam_devstep_f32(param, grad, mom, var, count, lr, beta1, beta2, eps, step_counter, stream);
+    }
+    rc = forward_body(batch, &model, w, st);
+    if (rc) return rc;
+    rc = gmc_head_f32(batch, w.Z0, w.zparts, model.b2, C, P, S, loss, w.GY2, w.db2part, stream);
+    if (rc) return rc;
+    AdamFuse af;
+    af.param = param; af.m = mom; af.v = var; af.lr = lr; af.beta1 = beta1; af.beta2 = beta2; af.eps = eps;
+    af.step_counter = step_counter;
+    return backward_body(batch, &model, w, grad, st, &af);
 }
 
 extern "C" int gmc_backward_from_gp(const gmc_batch *batch, const gmc_model *model, void *workspace,

@@ -1,0 +1,119 @@
+// "Finish" of the fused training step: fold the partial gradients and (optionally) apply Adam,
+// one launch over the flat parameter buffer [W1 | b1 | W2 | b2].
+//
+//   dW1[v,f]  = sum_chunk dw1part[chunk][v][f]          (v < n_max, else 0)
+//   dW2[f,k]  = sum_chunk colpart[chunk][f][k],  db1[f] = sum_chunk colpart[chunk][f][3]
+//   db2[k]    = sum_graph db2part[g][k]
+// all in ascending order (bitwise reproducible), then - when the optimizer pointers are given -
+// torch.optim.Adam.step (TrainingNeural.py:386) on the same element while it is in registers.
+// Replaces three tiny latency-bound launches (colsum, fold, adam) of the fused path by one.
+#include "gmc_common.h"
+#include <math.h>
+
+namespace {
+
+struct FinishArgs {
+    const float *dw1part;  // [chunks][n_max][F]
+    const float *colpart;  // [chunks][F][4]
+    const float *db2part;  // [B][3]
+    int chunks, n_max, N, F, B;
+    float *grad;           // flat
+    // Adam (param == nullptr: gradients only)
+    float *param, *m, *v;
+    double lr, beta1, beta2;
+    float eps;
+    const int *step_counter;  // device; the update uses *step_counter + 1
+};
+
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float w1, float b2, float w2,
+                                          float step_size, float bc2_sqrt, float eps) {
+    m = m + (g - m) * w1;
+    v = fmaf(w2 * g, g, v * b2);
+    p = p - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
+    __shared__ float sh[2];
+    const bool adam = a.param != nullptr;
+    if (adam && threadIdx.x == 0) {
+        const double t = (double)(*a.step_counter + 1);
+        sh[0] = (float)(a.lr / (1.0 - pow(a.beta1, t)));
+        sh[1] = (float)sqrt(1.0 - pow(a.beta2, t));
+    }
+    __syncthreads();
+    const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2);
+    const float step_size = adam ? sh[0] : 0.f, bc2_sqrt = adam ? sh[1] : 1.f;
+    const long nW1 = (long)a.N * a.F, live = (long)a.n_max * a.F;
+    const long n4 = nW1 >> 2;  // F % 4 == 0
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 g = gmc::f4_zero();
+        if (i * 4 < live) {  // chunk partials: 8 loads in flight, summed in ascending chunk order
+            const float4 *p = reinterpret_cast<const float4 *>(a.dw1part) + i;
+            const long cs = live >> 2;
+            for (int c0 = 0; c0 < a.chunks; c0 += 8) {
+                float4 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = c0 + u < a.chunks ? p[(long)(c0 + u) * cs] : gmc::f4_zero();
+#pragma unroll
+                for (int u = 0; u < 8; ++u) gmc::f4_add(g, t[u]);
+            }
+        }
+        reinterpret_cast<float4 *>(a.grad)[i] = g;
+        if (adam) {
+            float4 p = reinterpret_cast<float4 *>(a.param)[i];
+            float4 m = reinterpret_cast<float4 *>(a.m)[i];
+            float4 v = reinterpret_cast<float4 *>(a.v)[i];
+            adam_elem(p.x, g.x, m.x, v.x, w1, b2, w2, step_size, bc2_sqrt, a.eps);
+            adam_elem(p.y, g.y, m.y, v.y, w1, b2, w2, step_size, bc2_sqrt, a.eps);
+            adam_elem(p.z, g.z, m.z, v.z, w1, b2, w2, step_size, bc2_sqrt, a.eps);
+            adam_elem(p.w, g.w, m.w, v.w, w1, b2, w2, step_size, bc2_sqrt, a.eps);
+            reinterpret_cast<float4 *>(a.param)[i] = p;
+            reinterpret_cast<float4 *>(a.m)[i] = m;
+            reinterpret_cast<float4 *>(a.v)[i] = v;
+        }
+    }
+    // tail of the flat buffer: b1 [F], W2 [F,3], b2 [3]
+    const long tail = (long)a.F + (long)a.F * 3 + 3;
+    for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < tail; j += stride) {
+        float g = 0.f;
+        if (j < a.F) {  // db1[f]
+            for (int c = 0; c < a.chunks; ++c) g += a.colpart[((long)c * a.F + j) * 4 + 3];
+        } else if (j < (long)a.F * 4) {  // dW2[f,k]
+            const long e = j - a.F, f = e / 3, k = e % 3;
+            for (int c = 0; c < a.chunks; ++c) g += a.colpart[((long)c * a.F + f) * 4 + k];
+        } else {  // db2[k]
+            const int k = (int)(j - (long)a.F * 4);
+            for (int b = 0; b < a.B; ++b) g += a.db2part[b * 3 + k];
+        }
+        const long idx = nW1 + j;
+        a.grad[idx] = g;
+        if (adam) adam_elem(a.param[idx], g, a.m[idx], a.v[idx], w1, b2, w2, step_size, bc2_sqrt, a.eps);
+    }
+}
+
+__global__ void finish_tick_kernel(int *step_counter) { *step_counter += 1; }
+
+}  // namespace
+
+// param == nullptr -> gradients only.  step_counter (device) is advanced when Adam ran.
+int gmc_finish_launch(const float *dw1part, const float *colpart, const float *db2part, int chunks, int n_max,
+                      int N, int F, int B, float *grad, float *param, float *m, float *v, double lr, double beta1,
+                      double beta2, double eps, int *step_counter, hipStream_t st) {
+    FinishArgs a{dw1part, colpart, db2part, chunks, n_max, N, F, B, grad, param, m, v, lr, beta1, beta2, (float)eps,
+                 step_counter};
+    const long n4 = (long)N * F / 4;
+    long blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    {
+        GmcProbeScope probe(GMC_K_FINISH, st);
+        hipLaunchKernelGGL(finish_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+        GMC_LAUNCH_CHECK();
+    }
+    if (param) {
+        hipLaunchKernelGGL(finish_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
+        GMC_LAUNCH_CHECK();
+    }
+    return GMC_OK;
+}

@@ -51,15 +51,37 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16*4] *
     }
 }
 
+// neighbours of local row l: through the 16-byte ELL row (one load, padding ids >= n hit zeroed
+// slots) when the batch carries it, else the CSR row
+template <bool ELL, typename F>
+__device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l, int n, F &&f) {
+    if (ELL) {
+        const int W = b.ell_width;
+        const uint4 *row = reinterpret_cast<const uint4 *>(b.ell + (long)(r0 + l) * W);
+        for (int blk = 0; blk < W / 8; ++blk) {
+            const uint4 ids = row[blk];
+            const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
+                                    ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f((int)id[u], b.ell_vals ? b.ell_vals[(long)(r0 + l) * W + blk * 8 + u] : 1.0f);
+        }
+    } else {
+        for (int e = b.rowptr[r0 + l]; e < b.rowptr[r0 + l + 1]; ++e) f(b.lcol[e], b.vals ? b.vals[e] : 1.0f);
+    }
+    (void)n;
+}
+
+template <bool ELL>
 __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.x;
     const int r0 = a.b.goff[g];
     const int n = a.b.goff[g + 1] - r0;
-    float *sA = lds;                          // [n*3]  Z0, later dinv*GZ
-    float *sP = lds + 3 * a.b.n_max;          // [n*3]  softmax output
-    int *sS = reinterpret_cast<int *>(lds + 6 * a.b.n_max);  // [n] argmax class
-    float *red = lds + 7 * a.b.n_max;         // [64]
+    const int NP = a.b.n_max + 4;             // + 4 padding slots (ELL padding ids n..n+3): zeros / class 3
+    float *sA = lds;                          // [NP*3]  Z0, later dinv*GZ
+    float *sP = lds + 3 * NP;                 // [NP*3]  softmax output
+    int *sS = reinterpret_cast<int *>(lds + 6 * NP);  // [NP] argmax class
+    float *red = lds + 7 * NP;                // [64]
     const bool train = a.GY2 != nullptr;
 
     for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
@@ -67,17 +89,15 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         for (int p = 1; p < a.zparts; ++p) z += a.Z0[((long)p * a.b.R + r0) * 3 + i];
         sA[i] = z;
     }
+    if (threadIdx.x < 12) sA[3 * n + threadIdx.x] = 0.f;
+    if (threadIdx.x < 4) sS[n + threadIdx.x] = 3;  // a class no node has
     __syncthreads();
 
     // phase 1: aggregate, bias, softmax, override, argmax
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
-        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        for (int e = beg; e < end; ++e) {
-            const int c = a.b.lcol[e];
-            z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2];
-        }
+        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float) { z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2]; });
         const float d = a.b.dinv[r];
         z0 = fmaf(z0, d, a.b2[0]); z1 = fmaf(z1, d, a.b2[1]); z2 = fmaf(z2, d, a.b2[2]);
         const float m = fmaxf(z0, fmaxf(z1, z2));
@@ -104,15 +124,13 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // cut2, db2[0..2]
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
-        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
         const int me = sS[l];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, cut = 0.f;
-        for (int e = beg; e < end; ++e) {
-            const int sc = sS[a.b.lcol[e]];
-            const float w = a.b.vals ? a.b.vals[e] : 1.0f;
+        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float w) {
+            const int sc = sS[c];  // padding slots carry class 3: no contribution
             g0 += sc == 0 ? w : 0.f; g1 += sc == 1 ? w : 0.f; g2 += sc == 2 ? w : 0.f;
-            cut += sc != me ? w : 0.f;
-        }
+            cut += (sc != me && sc != 3) ? w : 0.f;
+        });
         acc[0] += cut;
         if (train) {
             g0 *= a.C; g1 *= a.C; g2 *= a.C;
@@ -136,12 +154,8 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     // phase 3: GY2 = A @ (dinv o GZ)   (A symmetric: A^T == A)
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
-        const int beg = a.b.rowptr[r], end = a.b.rowptr[r + 1];
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-        for (int e = beg; e < end; ++e) {
-            const int c = a.b.lcol[e];
-            y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2];
-        }
+        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
         *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, a.b.dinv[r]);
     }
 }
@@ -208,14 +222,18 @@ extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_p
     if (GY2 && !db2part) return GMC_ERR_NULL;
     if (batch->B == 0) return GMC_OK;
     HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part};
-    const size_t lds = sizeof(float) * (7 * (size_t)batch->n_max + 64);
+    const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
+    const bool ell = batch->ell != nullptr && batch->ell_width > 0;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(head_kernel),
+        hipError_t e = hipFuncSetAttribute(ell ? reinterpret_cast<const void *>(head_kernel<true>)
+                                               : reinterpret_cast<const void *>(head_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     GmcProbeScope probe(GMC_K_HEAD, static_cast<hipStream_t>(stream));
-    hipLaunchKernelGGL(head_kernel, dim3(batch->B), dim3(kHeadThreads), lds,
+    if (ell) hipLaunchKernelGGL(head_kernel<true>, dim3(batch->B), dim3(kHeadThreads), lds,
+                                static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(head_kernel<false>, dim3(batch->B), dim3(kHeadThreads), lds,
                        static_cast<hipStream_t>(stream), a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;

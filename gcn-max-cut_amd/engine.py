@@ -122,6 +122,26 @@ class FusedEngine:
         hip.check(rc, "gmc_train_fwd_bwd")
         return P, S, loss
 
+    def train_step(self, batch: GraphBatch, lr: float, C_: float = 1.0, out=None, betas=(0.9, 0.999),
+                   eps: float = 1e-8):
+        """One whole optimizer step (forward, loss, backward, fused gradient fold + Adam) - the
+        single-GPU form of the loop body of train_single_epoch (TrainingNeural.py:373-386).
+        Replay-invariant: the step number is read from / advanced in device memory."""
+        ws, nbytes = self._workspace(batch, True)
+        if out is None:
+            P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
+            S = torch.empty(batch.R, dtype=torch.int32, device=self.device)
+            loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
+        else:
+            P, S, loss = out
+        rc = self.lib.gmc_train_step_f32(batch.ref(), self.N, self.F, hip.ptr(self.flat), C_, hip.ptr(ws), nbytes,
+                                         hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad), hip.ptr(self.m),
+                                         hip.ptr(self.v), lr, betas[0], betas[1], eps, hip.ptr(self.step_dev),
+                                         hip.stream())
+        hip.check(rc, "gmc_train_step_f32")
+        self.step_count += 1
+        return P, S, loss
+
     def backward_from_gp(self, batch: GraphBatch, P: torch.Tensor, GP: torch.Tensor,
                          ws: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Gradients for a caller-supplied dLoss/dP (autograd path); ``ws`` must be the

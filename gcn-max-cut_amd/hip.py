@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GCN_MAXCUT_LIB") or os.path.join(_PKG, "lib", "libgcn
 SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
-    "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host",
+    "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_train_step_f32",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -65,6 +65,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_backward_from_gp.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), vp, sz, vp, vp, vp, vp]
     lib.gmc_adam_devstep_f32.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.gmc_ell_arrange_host.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp]
+    lib.gmc_train_step_f32.argtypes = [C.POINTER(GmcBatch), i32, i32, vp, f32, vp, sz, vp, vp, vp, vp, vp, vp,
+                                       C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.gmc_set_fuse.argtypes = [C.c_int]
     lib.gmc_decode_sample_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.gmc_probe_begin.argtypes = [i32]
@@ -124,7 +126,7 @@ def stream() -> int:
 
 
 KERNEL_TAGS = ("gather_w1", "agg_fwd", "head", "hidden_bwd", "colsum", "agg_bwd", "dw1", "dw1_fold",
-               "adam", "spmm_user", "dense_mfma", "bwd1_fused", "fwd1_fused", "decode")
+               "adam", "spmm_user", "dense_mfma", "bwd1_fused", "fwd1_fused", "decode", "finish")
 
 
 class Probe:

@@ -105,7 +105,8 @@ enum {
     GMC_K_BWD1_FUSED = 11, /* hidden backward + conv1 backward aggregation + dW1, one pass over H */
     GMC_K_FWD1_FUSED = 12, /* W1 gather + layer-1 aggregation (+ fused H@W2), one kernel */
     GMC_K_DECODE = 13,     /* post-processing sampler + cut count */
-    GMC_K_COUNT = 14
+    GMC_K_FINISH = 14,     /* fold of the gradient partials (+ fused Adam) over the flat buffer */
+    GMC_K_COUNT = 15
 };
 
 /* Timing probe for bench.py: between gmc_probe_begin and gmc_probe_end every kernel launch
@@ -183,6 +184,17 @@ int gmc_forward(const gmc_batch *batch, const gmc_model *model, float C, void *w
 int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C, void *workspace,
                       size_t workspace_bytes, float *P, int32_t *S, float *loss, float *grad,
                       gmc_stream_t stream);
+
+/* One whole optimizer step of train_single_epoch's loop body (:373-386) for the batch:
+ * gmc_train_fwd_bwd followed by Adam, with the gradient fold and the Adam update fused into
+ * one sweep over the flat buffers (param/grad/m/v, each N*F + F + F*3 + 3 floats, 16-byte
+ * aligned).  The step number lives in device memory as for gmc_adam_devstep_f32, so the call is
+ * replay-invariant (hipGraph).  Single-GPU form: with data parallelism the all-reduce has to
+ * sit between the gradient and Adam (gmc_train_fwd_bwd + all-reduce + gmc_adam_*). */
+int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, float *param, float C, void *workspace,
+                       size_t workspace_bytes, float *P, int32_t *S, float *loss, float *grad, float *m,
+                       float *v, double lr, double beta1, double beta2, double eps, int32_t *step_counter,
+                       gmc_stream_t stream);
 
 /* Backward for a caller-supplied dLoss/dP (autograd.Function path: callers that build
  * their own loss from GCNSoftmax.forward's output, e.g. the reference's
