@@ -22,7 +22,7 @@ struct FinishArgs {
     float *param, *m, *v;
     double lr, beta1, beta2;
     float eps;
-    const int *step_counter;  // device; the update uses *step_counter + 1
+    const int *step_counter;  // device; already advanced by this step's head launch: the update uses it as is
 };
 
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float w1, float b2, float w2,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     __shared__ float sh[2];
     const bool adam = a.param != nullptr;
     if (adam && threadIdx.x == 0) {
-        const double t = (double)(*a.step_counter + 1);
+        const double t = (double)(*a.step_counter);
         sh[0] = (float)(a.lr / (1.0 - pow(a.beta1, t)));
         sh[1] = (float)sqrt(1.0 - pow(a.beta2, t));
     }
@@ -92,11 +92,9 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     }
 }
 
-__global__ void finish_tick_kernel(int *step_counter) { *step_counter += 1; }
-
 }  // namespace
 
-// param == nullptr -> gradients only.  step_counter (device) is advanced when Adam ran.
+// param == nullptr -> gradients only.  *step_counter (device) must already hold this step's number.
 int gmc_finish_launch(const float *dw1part, const float *colpart, const float *db2part, int chunks, int n_max,
                       int N, int F, int B, float *grad, float *param, float *m, float *v, double lr, double beta1,
                       double beta2, double eps, int *step_counter, hipStream_t st) {
@@ -109,10 +107,6 @@ int gmc_finish_launch(const float *dw1part, const float *colpart, const float *d
     {
         GmcProbeScope probe(GMC_K_FINISH, st);
         hipLaunchKernelGGL(finish_kernel, dim3((int)blocks), dim3(256), 0, st, a);
-        GMC_LAUNCH_CHECK();
-    }
-    if (param) {
-        hipLaunchKernelGGL(finish_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
         GMC_LAUNCH_CHECK();
     }
     return GMC_OK;

@@ -28,6 +28,7 @@ struct HeadArgs {
     float *loss;
     float *GY2;
     float *db2part;
+    int *tick;  // optional device step counter, advanced once per launch (fused train step)
 };
 
 // Deterministic block sum of up to 4 values per thread; result valid in thread 0.
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     int *sS = reinterpret_cast<int *>(lds + 6 * NP);  // [NP] argmax class
     float *red = lds + 7 * NP;                // [64]
     const bool train = a.GY2 != nullptr;
+    if (a.tick && blockIdx.x == 0 && threadIdx.x == 0) *a.tick += 1;  // nobody reads it during this kernel
 
     for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
         float z = a.Z0[(long)r0 * 3 + i];
@@ -212,6 +214,10 @@ int check_batch(const gmc_batch *b) {
 
 }  // namespace
 
+// set by gmc_train_step_f32 right before its gmc_head_f32 call: the head launch then also advances
+// the device step counter (saves a one-thread "tick" launch per step)
+int *g_head_tick = nullptr;
+
 extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2,
                             float C, float *P, int32_t *S, float *loss, float *GY2, float *db2part,
                             gmc_stream_t stream) {
@@ -221,7 +227,8 @@ extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_p
     if (z_parts < 1) return GMC_ERR_SHAPE;
     if (GY2 && !db2part) return GMC_ERR_NULL;
     if (batch->B == 0) return GMC_OK;
-    HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part};
+    HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, g_head_tick};
+    g_head_tick = nullptr;
     const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
     const bool ell = batch->ell != nullptr && batch->ell_width > 0;
     if (lds > 64 * 1024) {
