@@ -13,7 +13,8 @@ int gmc_lds_slice_width(const gmc_batch *b);
 int gmc_dw1_chunks(int B, bool lds);
 int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
 bool gmc_bwd1_fits(const gmc_batch *b);
-extern int *g_head_tick;
+int gmc_head_launch(const gmc_batch *, const float *, int32_t, const float *, float, float *, int32_t *, float *,
+                    float *, float *, int *, hipStream_t);
 int gmc_finish_launch(const float *, const float *, const float *, int, int, int, int, int, float *, float *, float *,
                       float *, double, double, double, double, int *, hipStream_t);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
@@ -317,9 +318,8 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     }
     rc = forward_body(batch, &model, w, st);
     if (rc) return rc;
-    g_head_tick = step_counter;  // the head launch advances the step counter for the fused Adam
-    rc = gmc_head_f32(batch, w.Z0, w.zparts, model.b2, C, P, S, loss, w.GY2, w.db2part, stream);
-    g_head_tick = nullptr;
+    // the head launch advances the step counter for the fused Adam of the finish kernel
+    rc = gmc_head_launch(batch, w.Z0, w.zparts, model.b2, C, P, S, loss, w.GY2, w.db2part, step_counter, st);
     if (rc) return rc;
     AdamFuse af;
     af.param = param; af.m = mom; af.v = var; af.lr = lr; af.beta1 = beta1; af.beta2 = beta2; af.eps = eps;

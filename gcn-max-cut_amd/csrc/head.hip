@@ -214,21 +214,27 @@ int check_batch(const gmc_batch *b) {
 
 }  // namespace
 
-// set by gmc_train_step_f32 right before its gmc_head_f32 call: the head launch then also advances
-// the device step counter (saves a one-thread "tick" launch per step)
-int *g_head_tick = nullptr;
+// Internal launcher.  tick != nullptr: the launch also advances the device-side Adam step counter
+// (gmc_train_step_f32; saves a one-thread launch per step).
+int gmc_head_launch(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2, float C, float *P,
+                    int32_t *S, float *loss, float *GY2, float *db2part, int *tick, hipStream_t stream);
 
 extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2,
                             float C, float *P, int32_t *S, float *loss, float *GY2, float *db2part,
                             gmc_stream_t stream) {
+    return gmc_head_launch(batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, nullptr,
+                           static_cast<hipStream_t>(stream));
+}
+
+int gmc_head_launch(const gmc_batch *batch, const float *Z0, int32_t z_parts, const float *b2, float C, float *P,
+                    int32_t *S, float *loss, float *GY2, float *db2part, int *tick, hipStream_t stream) {
     int rc = check_batch(batch);
     if (rc) return rc;
     if (!Z0 || !b2 || !P) return GMC_ERR_NULL;
     if (z_parts < 1) return GMC_ERR_SHAPE;
     if (GY2 && !db2part) return GMC_ERR_NULL;
     if (batch->B == 0) return GMC_OK;
-    HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, g_head_tick};
-    g_head_tick = nullptr;
+    HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, tick};
     const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
     const bool ell = batch->ell != nullptr && batch->ell_width > 0;
     if (lds > 64 * 1024) {
@@ -237,11 +243,11 @@ extern "C" int gmc_head_f32(const gmc_batch *batch, const float *Z0, int32_t z_p
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    GmcProbeScope probe(GMC_K_HEAD, static_cast<hipStream_t>(stream));
+    GmcProbeScope probe(GMC_K_HEAD, stream);
     if (ell) hipLaunchKernelGGL(head_kernel<true>, dim3(batch->B), dim3(kHeadThreads), lds,
-                                static_cast<hipStream_t>(stream), a);
+                                stream, a);
     else hipLaunchKernelGGL(head_kernel<false>, dim3(batch->B), dim3(kHeadThreads), lds,
-                       static_cast<hipStream_t>(stream), a);
+                       stream, a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }

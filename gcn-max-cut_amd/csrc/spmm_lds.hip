@@ -61,9 +61,6 @@ extern "C" int gmc_debug_read_stamps(unsigned long long *out, int n) {
 namespace {
 
 constexpr int kThreads = 1024;
-#ifndef GMC_DBG
-#define GMC_DBG 0  // compile-time ablation mask for diagnostic builds: 2 no gather, 4 no store
-#endif
 
 struct TileArgs {
     gmc_batch b;
@@ -146,6 +143,13 @@ __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue
+// order): used to wait for a tile's DMA while the N stores issued after it stay in flight
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
+// for every global store of the wave to be acknowledged - what the tile loops must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int FS, int ACC>
 __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
@@ -200,6 +204,31 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
     return acc;
 }
 
+// gather_row with the row's ids already fetched (W == 8: one uint4).  Callers issue the id read of
+// their NEXT row before calling, so that it returns (LDS answers in order) under the same wait as
+// this row's eight reads and no row read ever sits behind an id read of its own.
+template <int FS, bool HAS_VAL>
+__device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids, const float *wrow, int q) {
+    constexpr int Q = FS / 4;
+    const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
+                            ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+    float4 x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[u] * Q + q];
+    float4 acc = gmc::f4_zero();
+    if (HAS_VAL) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow);
+        const float4 w1 = *reinterpret_cast<const float4 *>(wrow + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
+    }
+    return acc;
+}
+
 // ACC = rows per thread (ACC * rows-per-pass >= n_max).
 //
 // Slice loop, software-pipelined so that no wait ever covers a freshly issued memory op
@@ -250,64 +279,59 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     dma_wait();
     __syncthreads();
 
-    float4 y[ACC];
-    // gather + epilogue of slice s from tile buffer `cur` into y (and the fused-W2 partials)
+    // gather + epilogue + store of slice s from tile buffer `cur` (and the fused-W2 partials).
+    // Every wave issues exactly ACC store instructions per slice - rows past n repeat row n-1 (same
+    // value to the same address) and a wave always holds lanes of in-range columns - which is what
+    // lets the loop wait for the younger-by-ACC DMA with a counted vmcnt.
     auto compute = [&](int s, int cur) {
         const float *tile = lds + cur * TF;
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
+        const bool col_on = s * FS + 4 * q < a.F;
+        float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
+        float4 wa, wb, wc;
+        if (EPI) {  // W2 rows of my 4 columns from LDS (zero for pad columns)
+            wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
+            wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
+            wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+        }
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
-            const int l = min(lrow + k * kRowsPerPass, n - 1);  // rows past the end redo row n-1 (never stored)
-            float4 acc = gmc::f4_zero();
-            if (!(GMC_DBG & 2)) acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
-            y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
-            y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
+            const int l = min(lrow + k * kRowsPerPass, n - 1);
+            const float4 acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            float4 y;
+            y.x = fmaf(acc.x, sc[k], bias.x); y.y = fmaf(acc.y, sc[k], bias.y);
+            y.z = fmaf(acc.z, sc[k], bias.z); y.w = fmaf(acc.w, sc[k], bias.w);
             if (a.relu) {
-                y[k].x = y[k].x > 0.f ? y[k].x : 0.f; y[k].y = y[k].y > 0.f ? y[k].y : 0.f;
-                y[k].z = y[k].z > 0.f ? y[k].z : 0.f; y[k].w = y[k].w > 0.f ? y[k].w : 0.f;
+                y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
+                y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
             }
-            if (EPI) {  // W2 rows of my 4 columns from LDS; pad columns (>= F) may hold anything
-                if (s * FS + 4 * q >= a.F) y[k] = gmc::f4_zero();
-                const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
-                const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
-                const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
-                zr[k][0] += y[k].x * wa.x + y[k].y * wa.w + y[k].z * wb.z + y[k].w * wc.y;
-                zr[k][1] += y[k].x * wa.y + y[k].y * wb.x + y[k].z * wb.w + y[k].w * wc.z;
-                zr[k][2] += y[k].x * wa.z + y[k].y * wb.y + y[k].z * wc.x + y[k].w * wc.w;
+            if (col_on) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+            if (EPI) {
+                zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
+                zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
+                zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
             }
         }
     };
-    auto store = [&](int s) {
-        const int c = s * FS + 4 * q;
-#pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            if (l < n && c < a.F && !(GMC_DBG & 4))
-                *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)s * a.y_ss + 4 * q) = y[k];
-        }
-    };
-    auto prefetch = [&](int s, int into) {  // clamped: past the last slice re-read it (L2 hit, never used)
-        const int sc_ = min(s, s_end - 1);
-        dma_tile<FS, ACC>(src0 + sc_ * a.x_ss, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, lds + into * TF);
+    auto prefetch = [&](int s, int into) {
+        dma_tile<FS, ACC>(src0 + s * a.x_ss, a.x_rs, n, s * FS + 4 * q < a.F, lrow, lds + into * TF);
     };
 
-    // peeled first slice, then the steady state: DMA of slice s+1 and stores of slice s-1 are
-    // issued first, the LDS gather of slice s runs while they are in flight, and the barrier's
-    // vmcnt(0) retires them
-    prefetch(s_beg + 1, 1);
-    compute(s_beg, 0);
-    dma_wait();
-    __syncthreads();
-    for (int s = s_beg + 1; s < s_end; ++s) {
+    // Steady state: the DMA of slice s+1 is issued first, the LDS gather of slice s runs while it is
+    // in flight and stores each row as it is finished; the wait then covers the DMA only (vector
+    // memory operations retire in issue order, the ACC stores are younger) and the barrier orders
+    // LDS traffic only, so no wave ever waits for a store to be acknowledged.
+    for (int s = s_beg; s < s_end; ++s) {
         const int cur = (s - s_beg) & 1;
-        prefetch(s + 1, cur ^ 1);
-        store(s - 1);
+        const bool more = s + 1 < s_end;
+        if (more) prefetch(s + 1, cur ^ 1);
         compute(s, cur);
-        dma_wait();
-        __syncthreads();   // next tile landed; everyone is done reading this one
+        if (more) {
+            vm_wait<ACC>();
+            lds_barrier();  // next tile landed; everyone is done reading this one
+        }
     }
-    store(s_end - 1);
     if (EPI) {  // fold the row's Q lanes (fixed xor tree), one partial per slice group
         float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
     for (int k = 0; k < ACC; ++k) {
         const int l = lrow + k * kRowsPerPass;
-        sc[k] = l < n ? a.scale[r0 + l] : 1.0f;
+        sc[k] = a.scale[r0 + min(l, n - 1)];
     }
     for (int i = threadIdx.x; i < per * FS; i += kThreads) {
         const int c = s_beg * FS + i;
@@ -463,72 +487,84 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     }
     load_table<FS, W>(a.b, r0, n, bufA, bufB, nb);
 
-    float4 y[ACC];
     STAMP_DECL;
+    dma_wait();  // table / constants / first tile
     for (int s = s_beg; s < s_end; ++s) {
         STAMP(0);  // loop overhead / previous tail
-        dma_wait();
+        // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
+        if (s > s_beg) vm_wait<ACC>();
         STAMP(1);  // DMA wait
-        __syncthreads();  // W1 tile of slice s landed; readers of the previous T0 tile are done
+        lds_barrier();  // ... for every wave; readers of the previous T0 tile are done
         STAMP(2);  // barrier 1
         // gather #1: T0 tile
-#pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            if (l < n) {
-                float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
-                t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
-                reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
-            }
-        }
-        STAMP(3);  // gather 1
-        __syncthreads();
-        STAMP(4);  // barrier 2
-        if (s > s_beg) {  // stores of the previous slice
-            const int c = (s - 1) * FS + 4 * q;
+        if constexpr (W == 8) {
+            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = lrow + k * kRowsPerPass;
-                if (l < n && c < a.F)
-                    *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)(s - 1) * a.y_ss + 4 * q) = y[k];
+                const uint4 cur = ids;
+                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                if (l < n) {
+                    float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)l * W : nullptr, q);
+                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                    reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n) {
+                    float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                    reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+                }
             }
         }
-        dma(s + 1);  // buffer A is free: next W1 tile streams in during gather #2 (issued after the
-                     // stores so that no compiler-inserted wait between them can drain it)
-        STAMP(5);  // stores + DMA issue
-        // gather #2: H tile rows + fused W2
+        STAMP(3);  // gather 1
+        lds_barrier();
+        STAMP(4);  // barrier 2
+        if (s + 1 < s_end) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+        STAMP(5);  // DMA issue
+        // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
+        // row n-1: same value to the same address) so that the vm_wait above counts exactly
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
+        const bool col_pad = s * FS + 4 * q >= a.F;  // slab pad columns: stored as zeros
+        float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
+        const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
+        const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
+        const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+        auto emit = [&](int k, const float4 acc) {
+            const int l = min(lrow + k * kRowsPerPass, n - 1);
+            float4 y;
+            y.x = fmaf(acc.x, sc[k], bias.x); y.y = fmaf(acc.y, sc[k], bias.y);
+            y.z = fmaf(acc.z, sc[k], bias.z); y.w = fmaf(acc.w, sc[k], bias.w);
+            if (a.relu) {
+                y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
+                y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
+            }
+            if (col_pad) y = gmc::f4_zero();
+            *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+            zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
+            zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
+            zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
+        };
+        uint4 ids2 = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);
-            const float4 acc = gather_row<FS, W, false>(bufB, nb, nullptr, l, q);
-            y[k].x = fmaf(acc.x, sc[k], bias.x); y[k].y = fmaf(acc.y, sc[k], bias.y);
-            y[k].z = fmaf(acc.z, sc[k], bias.z); y[k].w = fmaf(acc.w, sc[k], bias.w);
-            if (a.relu) {
-                y[k].x = y[k].x > 0.f ? y[k].x : 0.f; y[k].y = y[k].y > 0.f ? y[k].y : 0.f;
-                y[k].z = y[k].z > 0.f ? y[k].z : 0.f; y[k].w = y[k].w > 0.f ? y[k].w : 0.f;
+            if constexpr (W == 8) {
+                const uint4 cur = ids2;
+                if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                emit(k, gather_ids8<FS, false>(bufB, cur, nullptr, q));
+            } else {
+                emit(k, gather_row<FS, W, false>(bufB, nb, nullptr, l, q));
             }
-            if (s * FS + 4 * q >= a.F) y[k] = gmc::f4_zero();  // pad columns may hold anything
-            const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
-            const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
-            const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
-            zr[k][0] += y[k].x * wa.x + y[k].y * wa.w + y[k].z * wb.z + y[k].w * wc.y;
-            zr[k][1] += y[k].x * wa.y + y[k].y * wb.x + y[k].z * wb.w + y[k].w * wc.z;
-            zr[k][2] += y[k].x * wa.z + y[k].y * wb.y + y[k].z * wc.x + y[k].w * wc.w;
         }
         STAMP(6);  // gather 2
     }
     STAMP_FLUSH;
-    {   // stores of the last slice
-        const int c = (s_end - 1) * FS + 4 * q;
-#pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            if (l < n && c < a.F)
-                *reinterpret_cast<float4 *>(a.Y + (long)(r0 + l) * a.y_rs + (long)(s_end - 1) * a.y_ss + 4 * q) = y[k];
-        }
-    }
     if (a.Zpart) {
         float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
