@@ -346,6 +346,7 @@ class FusedTrainer:
         self._out = (torch.empty((rmax, 3), dtype=torch.float32, device=dev),
                      torch.empty(rmax, dtype=torch.int32, device=dev))
         self._loss_slots = torch.zeros((len(self._batches), max(bmax, 1)), dtype=torch.float32, device=dev)
+        self._step_loss = torch.zeros(len(self._batches), dtype=torch.float32, device=dev)
         self._plan_key = key
         self._graph = None
 
@@ -359,15 +360,16 @@ class FusedTrainer:
             eng.step_dev.fill_(eng.step_count)
             self._enqueue_epoch()
         else:
+            tail = eng.grad[eng.count:eng.count + 1]   # the step's loss rides in the gradient all-reduce
             for i, batch in enumerate(self._batches):
                 eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
                 if self.world > 1:
+                    torch.sum(self._loss_slots[i, :batch.B], dim=0, keepdim=True, out=tail)
                     eng.allreduce_grad()
+                    self._step_loss[i:i + 1].copy_(tail)
                 eng.adam_step(cfg.learning_rate)
         if self.world > 1:
-            per_step = self._loss_slots.sum(dim=1)
-            dist.all_reduce(per_step, op=dist.ReduceOp.SUM)
-            return float(sum(per_step.cpu().tolist()))
+            return float(sum(self._step_loss.cpu().tolist()))   # one host sync per epoch
         # one device->host copy per epoch; the reference adds one float per optimizer step
         # (loss.item(), :388), each the sum of that step's per-graph losses
         host = self._loss_slots.cpu().numpy()

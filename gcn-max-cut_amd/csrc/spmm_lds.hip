@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
             }
             if (col_on) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
             if (EPI) {
+                if (!col_on) y = gmc::f4_zero();  // pad columns of the tile may hold anything (NaN * 0)
                 zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
                 zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
                 zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
@@ -467,10 +468,7 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
     const float *src0 = a.X + 4 * q;  // W1, row-major [N][ldx]
 
-    auto dma = [&](int s) {  // clamped past the last slice (L2 hit, never used)
-        const int sc_ = min(s, s_end - 1);
-        dma_tile<FS, ACC>(src0 + sc_ * FS, a.x_rs, n, sc_ * FS + 4 * q < a.F, lrow, bufA);
-    };
+    auto dma = [&](int s) { dma_tile<FS, ACC>(src0 + s * FS, a.x_rs, n, s * FS + 4 * q < a.F, lrow, bufA); };
     dma(s_beg);
     float zr[ACC][3] = {};
     float sc[ACC];
