@@ -176,26 +176,46 @@ __device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, fl
     }
 }
 
+// Read the eight tile rows named by eight packed u16 ids (lane's 16 B of each row).  The byte
+// address id * row_bytes + (tile + 16 q) is one v_mad_u32_u16 per row (op_sel picks the id's half
+// of the dword) instead of the unpack + shift-add pair the compiler emits: the gathers spend about
+// as many SIMD cycles on address arithmetic and adds as LDS cycles on the reads.
+__device__ __forceinline__ void read8(const float *tile, int q, unsigned row_bytes, const uint4 ids, float4 (&x)[8]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    using lds_f4 = __attribute__((address_space(3))) const v4f;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
+    const unsigned pk[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned lo, hi;
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(lo) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+        const v4f a = *(lds_f4 *)(size_t)lo, b = *(lds_f4 *)(size_t)hi;
+        x[2 * j] = make_float4(a.x, a.y, a.z, a.w);
+        x[2 * j + 1] = make_float4(b.x, b.y, b.z, b.w);
+    }
+}
+
 // sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
 template <int FS, int W, bool HAS_VAL>
 __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
                                              int l, int q) {
-    constexpr int Q = FS / 4;
     float4 acc = gmc::f4_zero();
 #pragma unroll
     for (int blk = 0; blk < W / 8; ++blk) {
         const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
-        const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
-                                ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
         float4 x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[u] * Q + q];
+        read8(tile, q, FS * 4, ids, x);
         if (HAS_VAL) {  // weights come from HBM/L2: this (rare) variant waits on them per row
             const float4 w0 = *reinterpret_cast<const float4 *>(wrow + blk * 8);
             const float4 w1 = *reinterpret_cast<const float4 *>(wrow + blk * 8 + 4);
             const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+        } else if (blk == 0) {
+            acc = x[0];  // not 0 + x[0]: the compiler may not drop an add of +0.0
+#pragma unroll
+            for (int u = 1; u < 8; ++u) gmc::f4_add(acc, x[u]);
         } else {
 #pragma unroll
             for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
@@ -209,22 +229,20 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
 // this row's eight reads and no row read ever sits behind an id read of its own.
 template <int FS, bool HAS_VAL>
 __device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids, const float *wrow, int q) {
-    constexpr int Q = FS / 4;
-    const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
-                            ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
     float4 x[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) x[u] = reinterpret_cast<const float4 *>(tile)[id[u] * Q + q];
-    float4 acc = gmc::f4_zero();
+    read8(tile, q, FS * 4, ids, x);
+    float4 acc;
     if (HAS_VAL) {
         const float4 w0 = *reinterpret_cast<const float4 *>(wrow);
         const float4 w1 = *reinterpret_cast<const float4 *>(wrow + 4);
         const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        acc = make_float4(w[0] * x[0].x, w[0] * x[0].y, w[0] * x[0].z, w[0] * x[0].w);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+        for (int u = 1; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
     } else {
+        acc = x[0];  // not 0 + x[0]: the compiler may not drop an add of +0.0
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
+        for (int u = 1; u < 8; ++u) gmc::f4_add(acc, x[u]);
     }
     return acc;
 }
