@@ -44,6 +44,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// max(x, 0) as ONE v_max_f32 (the C++ forms compile to a canonicalising v_max x,x plus the max)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_add(float4 &a, const float4 &b) {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

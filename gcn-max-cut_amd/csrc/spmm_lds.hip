@@ -212,13 +212,13 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
             const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
             for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
-        } else if (blk == 0) {
-            acc = x[0];  // not 0 + x[0]: the compiler may not drop an add of +0.0
+        } else if (blk == 0) {  // last read first: one wait per block (see gather_ids8)
+            acc = x[7];
 #pragma unroll
-            for (int u = 1; u < 8; ++u) gmc::f4_add(acc, x[u]);
+            for (int u = 6; u >= 0; --u) gmc::f4_add(acc, x[u]);
         } else {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
+            for (int u = 7; u >= 0; --u) gmc::f4_add(acc, x[u]);
         }
     }
     return acc;
@@ -240,9 +240,14 @@ __device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids
 #pragma unroll
         for (int u = 1; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
     } else {
-        acc = x[0];  // not 0 + x[0]: the compiler may not drop an add of +0.0
+        // Summed from the last read back: the first add then waits for all eight reads at once
+        // (LDS answers in order) and the row costs one s_waitcnt instead of eight.  These kernels
+        // are instruction-issue bound (rocprofv3: some instruction active 84 % of SIMD time), so
+        // every instruction saved per row counts.  Starts from x[7], not 0 + x[7]: the compiler
+        // may not drop an add of +0.0.
+        acc = x[7];
 #pragma unroll
-        for (int u = 1; u < 8; ++u) gmc::f4_add(acc, x[u]);
+        for (int u = 6; u >= 0; --u) gmc::f4_add(acc, x[u]);
     }
     return acc;
 }
@@ -278,6 +283,8 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
 
     dma_tile<FS, ACC>(src0 + s_beg * a.x_ss, a.x_rs, n, s_beg * FS + 4 * q < a.F, lrow, lds);
 
+    // prologue: every global read is issued before the first use, so the workgroup pays one memory
+    // latency (not one per table) before its first gather
     float zr[EPI ? ACC : 1][3] = {};
     float sc[ACC];
 #pragma unroll
@@ -285,15 +292,40 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         const int l = lrow + k * kRowsPerPass;
         sc[k] = (a.scale && l < n) ? a.scale[r0 + l] : 1.0f;
     }
-    for (int i = threadIdx.x; i < per * FS; i += kThreads) {  // column constants of my slices -> LDS
-        const int c = s_beg * FS + i;
-        cbias[i] = (a.bias && c < a.F) ? a.bias[c] : 0.f;
-        if (EPI) {
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
+    uint4 pt[NT];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) cw2[3 * i + j] = c < a.F ? a.W2[(long)c * 3 + j] : 0.f;
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
         }
     }
-    load_table<FS, W>(a.b, r0, n, lds, lds + TF, nb);
+    const int ci = threadIdx.x, cc = s_beg * FS + ci;  // column constants of my slices (per * FS <= kThreads)
+    const bool c_on = ci < per * FS;
+    const float cb = (c_on && a.bias && cc < a.F) ? a.bias[cc] : 0.f;
+    float cw[3] = {0.f, 0.f, 0.f};
+    if (EPI && c_on && cc < a.F) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cw[j] = a.W2[(long)cc * 3 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int i = threadIdx.x + k * kThreads;
+        if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+    }
+    if (c_on) {
+        cbias[ci] = cb;
+        if (EPI) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cw2[3 * ci + j] = cw[j];
+        }
+    }
+    if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
+        lds[(long)n * FS + threadIdx.x] = 0.f;
+        lds[TF + (long)n * FS + threadIdx.x] = 0.f;
+    }
     dma_wait();
     __syncthreads();
 
@@ -466,6 +498,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
 // writes H once and reads only W1 (from L2) and the neighbour table.
 template <int FS, int W, int ACC, bool HAS_VAL>
 __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
+    STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
@@ -484,9 +517,11 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     float *cw2 = cbias + per * FS;
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
-    const float *src0 = a.X + 4 * q;  // W1, row-major [N][ldx]
-
-    auto dma = [&](int s) { dma_tile<FS, ACC>(src0 + s * FS, a.x_rs, n, s * FS + 4 * q < a.F, lrow, bufA); };
+    // W1 tile of slice s, row-major [N][ldx].  Pad columns (>= F, last slice only) load the last valid
+    // column group again: finite values, so that the masked scale below turns them into exact zeros
+    auto dma = [&](int s) {
+        dma_tile<FS, ACC>(a.X + min(s * FS + 4 * q, a.F - 4), a.x_rs, n, true, lrow, bufA);
+    };
     dma(s_beg);
     float zr[ACC][3] = {};
     float sc[ACC];
@@ -495,16 +530,42 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
         const int l = lrow + k * kRowsPerPass;
         sc[k] = a.scale[r0 + min(l, n - 1)];
     }
-    for (int i = threadIdx.x; i < per * FS; i += kThreads) {
-        const int c = s_beg * FS + i;
-        cbias[i] = (a.bias && c < a.F) ? a.bias[c] : 0.f;
+    // prologue: every global read is issued before the first use (one memory latency, not three)
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
+    uint4 pt[NT];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) cw2[3 * i + j] = (a.W2 && c < a.F) ? a.W2[(long)c * 3 + j] : 0.f;
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
     }
-    load_table<FS, W>(a.b, r0, n, bufA, bufB, nb);
+    const int ci = threadIdx.x, cc = s_beg * FS + ci;  // column constants of my slices (per * FS <= kThreads)
+    const bool c_on = ci < per * FS;
+    const float cb = (c_on && a.bias && cc < a.F) ? a.bias[cc] : 0.f;
+    float cw[3] = {0.f, 0.f, 0.f};
+    if (c_on && a.W2 && cc < a.F) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cw[j] = a.W2[(long)cc * 3 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int i = threadIdx.x + k * kThreads;
+        if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+    }
+    if (c_on) {
+        cbias[ci] = cb;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cw2[3 * ci + j] = cw[j];
+    }
+    if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
+        bufA[(long)n * FS + threadIdx.x] = 0.f;
+        bufB[(long)n * FS + threadIdx.x] = 0.f;
+    }
 
-    STAMP_DECL;
     dma_wait();  // table / constants / first tile
+    STAMP(11);  // prologue
     for (int s = s_beg; s < s_end; ++s) {
         STAMP(0);  // loop overhead / previous tail
         // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
@@ -520,11 +581,11 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                 const int l = lrow + k * kRowsPerPass;
                 const uint4 cur = ids;
                 if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                if (l < n) {
-                    float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)l * W : nullptr, q);
-                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
-                    reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
-                }
+                // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
+                const int lc = min(l, n - 1);
+                float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
             }
         } else {
 #pragma unroll
@@ -551,16 +612,16 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
         const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
         const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
         const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+        // pad columns: finite tile values (see dma) * scale 0 + bias 0 = exact zeros, no per-row select
+        float scm[ACC];
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
         auto emit = [&](int k, const float4 acc) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);
             float4 y;
-            y.x = fmaf(acc.x, sc[k], bias.x); y.y = fmaf(acc.y, sc[k], bias.y);
-            y.z = fmaf(acc.z, sc[k], bias.z); y.w = fmaf(acc.w, sc[k], bias.w);
-            if (a.relu) {
-                y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
-                y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
-            }
-            if (col_pad) y = gmc::f4_zero();
+            y.x = fmaf(acc.x, scm[k], bias.x); y.y = fmaf(acc.y, scm[k], bias.y);
+            y.z = fmaf(acc.z, scm[k], bias.z); y.w = fmaf(acc.w, scm[k], bias.w);
+            y.x = gmc::relu1(y.x); y.y = gmc::relu1(y.y); y.z = gmc::relu1(y.z); y.w = gmc::relu1(y.w);  // F.relu, :81
             *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
             zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
             zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
@@ -580,7 +641,6 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
         }
         STAMP(6);  // gather 2
     }
-    STAMP_FLUSH;
     if (a.Zpart) {
         float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
@@ -596,6 +656,8 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
             }
         }
     }
+    STAMP(7);  // epilogue
+    STAMP_FLUSH;
 }
 
 // ---- fused layer-1 backward: hidden backward + aggregation + dW1 in one pass over H --------
