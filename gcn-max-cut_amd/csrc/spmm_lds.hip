@@ -744,30 +744,41 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         const int n = a.b.goff[g + 1] - r0;
         float dv[ACC];
         STAMP(0);
-        // (1) H -> Gs in place + column partials
+        // (1) H -> Gs in place + column partials.  The row constants (GY2[r,:], dinv[r]) of all my rows
+        // are requested before the first use: one memory latency per graph, not one per row.  Pad
+        // columns need no masks: their W2 rows are 0 here and the H slab holds exact zeros there.
+#ifndef GMC_BWD1_RC
+#define GMC_BWD1_RC 1  // rows whose constants are requested together (more = fewer latencies but spills)
+#endif
+        constexpr int RCB = GMC_BWD1_RC < 1 ? 1 : (GMC_BWD1_RC > ACC ? ACC : GMC_BWD1_RC);
+        float4 rc[RCB];
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
+            if (k % RCB == 0) {
+#pragma unroll
+                for (int j = 0; j < RCB; ++j)
+                    if (k + j < ACC)
+                        rc[j] = *reinterpret_cast<const float4 *>(a.GY2 + (long)(r0 + min(lrow + (k + j) * kRowsPerPass, n - 1)) * 4);
+            }
             const int l = lrow + k * kRowsPerPass;
-            dv[k] = 1.f;
-            if (l < n) {
-                const int r = r0 + l;
-                const float4 rcst = *reinterpret_cast<const float4 *>(a.GY2 + (long)r * 4);  // (GY2[r,:], dinv[r])
-                const float gy0 = rcst.x, gy1 = rcst.y, gy2 = rcst.z, d = rcst.w;
-                dv[k] = d;
+            const float4 rck = rc[k % RCB];
+            const float d = rck.w;
+            dv[k] = d;
+            if (l < n) {  // in place: rows past n must not touch row n-1 again
+                const float gd[3] = {rck.x * d, rck.y * d, rck.z * d};
                 float4 *cell = reinterpret_cast<float4 *>(bufA) + l * Q + q;
                 const float4 h = *cell;
                 const float hv[4] = {h.x, h.y, h.z, h.w};
                 float gs[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float gh = gy0 * w2[j][0] + gy1 * w2[j][1] + gy2 * w2[j][2];
-                    const float gpre = (col_on && hv[j] > 0.f) ? gh * d : 0.f;
+                    const float ghd = gd[0] * w2[j][0] + gd[1] * w2[j][1] + gd[2] * w2[j][2];
+                    const float gpre = hv[j] > 0.f ? ghd : 0.f;  // relu' o dinv o (GY2 W2^T)
                     gs[j] = gpre * d;
-                    const float hd = col_on ? hv[j] * d : 0.f;
-                    colp[4 * j + 0] = fmaf(hd, gy0, colp[4 * j + 0]);
-                    colp[4 * j + 1] = fmaf(hd, gy1, colp[4 * j + 1]);
-                    colp[4 * j + 2] = fmaf(hd, gy2, colp[4 * j + 2]);
-                    colp[4 * j + 3] += gpre;
+                    colp[4 * j + 0] = fmaf(hv[j], gd[0], colp[4 * j + 0]);  // dW2 = (H o dinv)^T GY2
+                    colp[4 * j + 1] = fmaf(hv[j], gd[1], colp[4 * j + 1]);
+                    colp[4 * j + 2] = fmaf(hv[j], gd[2], colp[4 * j + 2]);
+                    colp[4 * j + 3] += gpre;                                // db1
                 }
                 *cell = make_float4(gs[0], gs[1], gs[2], gs[3]);
             }
@@ -775,14 +786,27 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         STAMP(1);  // transform
         __syncthreads();
         STAMP(2);  // barrier A
-        // (2) U tile = dinv o (A @ Gs)
+        // (2) U tile = dinv o (A @ Gs); rows past n redo row n-1 (same value to the same address)
+        if constexpr (W == 8) {
+            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            if (l < n) {
-                float4 u = gather_row<FS, W, false>(bufA, nb, nullptr, l, q);
+            for (int k = 0; k < ACC; ++k) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                const uint4 cur = ids;
+                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                float4 u = gather_ids8<FS, false>(bufA, cur, nullptr, q);
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n) {
+                    float4 u = gather_row<FS, W, false>(bufA, nb, nullptr, l, q);
+                    u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
+                    reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+                }
             }
         }
         STAMP(3);  // gather 1
@@ -792,10 +816,21 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         if (g + 1 < g1) fetch(g + 1);
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+        if constexpr (W == 8) {
+            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                const uint4 cur = ids;
+                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                if (l < n) gmc::f4_add(acc[k], gather_ids8<FS, HAS_VAL>(bufB, cur, HAS_VAL ? wbase + (long)l * W : nullptr, q));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+            }
         }
         STAMP(6);  // gather 2
         dma_wait();
