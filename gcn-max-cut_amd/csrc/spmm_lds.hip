@@ -123,9 +123,11 @@ constexpr int kPadRows = 4;
 __host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + kPadRows) * FS; }
 constexpr int kMaxSlicesPerWg = 8;
 size_t lds_bytes(int n_max, int W, int FS) {
-    // + the larger of: bias and W2 rows of up to kMaxSlicesPerWg slices (spmm: 8 * FS * 16 B) and
-    // the cross-wave fold area of bwd1 (16 waves * FS/4 lanes * 16 floats = 256 * FS B)
-    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (size_t)256 * FS;
+    // + the larger of: bias and W2 rows of up to kMaxSlicesPerWg slices (spmm / fwd1: 8 * FS * 16 B)
+    // and the per-row constants (GY2[r,:], dinv[r]) of the graph in flight (bwd1: 16 B per row; its
+    // cross-wave fold area of 256 * FS B re-uses a tile buffer after the graph loop)
+    const size_t consts = (size_t)256 * FS, rows = (size_t)16 * (n_max + kPadRows);
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (consts > rows ? consts : rows);
 }
 
 // Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
@@ -694,7 +696,8 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
     unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
-    float *red = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [16 waves][Q][16]
+    float *gyl = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [n][4] = (GY2[r,:], dinv[r]) of the graph
+    float *red = bufB;  // [16 waves][Q][16] cross-wave fold area, used after the graph loop
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const int f0 = s * FS + 4 * q;
     const bool col_on = f0 < a.F;
@@ -716,6 +719,13 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
         dma_tile<FS, ACC>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+        {   // the graph's row constants, 16 B per row, by the same DMA path (lane i -> row i)
+            const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)gyl;
+            for (int i0 = 0; i0 < n; i0 += kThreads) {
+                const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (unsigned)(i0 + (threadIdx.x & ~63u))));
+                if (i0 + (int)threadIdx.x < n) glds16(a.GY2 + (long)(r0 + i0 + threadIdx.x) * 4, dst);
+            }
+        }
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
@@ -744,24 +754,13 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         const int n = a.b.goff[g + 1] - r0;
         float dv[ACC];
         STAMP(0);
-        // (1) H -> Gs in place + column partials.  The row constants (GY2[r,:], dinv[r]) of all my rows
-        // are requested before the first use: one memory latency per graph, not one per row.  Pad
-        // columns need no masks: their W2 rows are 0 here and the H slab holds exact zeros there.
-#ifndef GMC_BWD1_RC
-#define GMC_BWD1_RC 1  // rows whose constants are requested together (more = fewer latencies but spills)
-#endif
-        constexpr int RCB = GMC_BWD1_RC < 1 ? 1 : (GMC_BWD1_RC > ACC ? ACC : GMC_BWD1_RC);
-        float4 rc[RCB];
+        // (1) H -> Gs in place + column partials.  The row constants (GY2[r,:], dinv[r]) came with the
+        // tile by DMA: an LDS read per row instead of a global-memory latency per row.  Pad columns
+        // need no masks: their W2 rows are 0 here and the H slab holds exact zeros there.
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
-            if (k % RCB == 0) {
-#pragma unroll
-                for (int j = 0; j < RCB; ++j)
-                    if (k + j < ACC)
-                        rc[j] = *reinterpret_cast<const float4 *>(a.GY2 + (long)(r0 + min(lrow + (k + j) * kRowsPerPass, n - 1)) * 4);
-            }
             const int l = lrow + k * kRowsPerPass;
-            const float4 rck = rc[k % RCB];
+            const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
             const float d = rck.w;
             dv[k] = d;
             if (l < n) {  // in place: rows past n must not touch row n-1 again
