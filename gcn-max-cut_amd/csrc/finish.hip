@@ -3,8 +3,8 @@
 //
 //   dW1[v,f]  = sum_chunk dw1part[chunk][v][f]          (v < n_max, else 0)
 //   dW2[f,k]  = sum_chunk colpart[chunk][f][k],  db1[f] = sum_chunk colpart[chunk][f][3]
-//   db2[k]    = sum_graph db2part[g][k]
-// all in ascending order (bitwise reproducible), then - when the optimizer pointers are given -
+//   db2[k]    = sum_graph db2part[g][k]          (lane-strided partial sums + fixed tree)
+// all in a fixed order (bitwise reproducible), then - when the optimizer pointers are given -
 // torch.optim.Adam.step (TrainingNeural.py:386) on the same element while it is in registers.
 // Replaces three tiny latency-bound launches (colsum, fold, adam) of the fused path by one.
 #include "gmc_common.h"
@@ -47,23 +47,28 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
     const long n4 = nW1 >> 2;  // F % 4 == 0
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
+        // every read of the element is requested before the first use: the launch is short and
+        // latency-bound, so it pays one memory round trip, not one per batch of partials
+        float4 p, m, v;
+        if (adam) {
+            p = reinterpret_cast<const float4 *>(a.param)[i];
+            m = reinterpret_cast<const float4 *>(a.m)[i];
+            v = reinterpret_cast<const float4 *>(a.v)[i];
+        }
         float4 g = gmc::f4_zero();
-        if (i * 4 < live) {  // chunk partials: 8 loads in flight, summed in ascending chunk order
-            const float4 *p = reinterpret_cast<const float4 *>(a.dw1part) + i;
+        if (i * 4 < live) {  // chunk partials, summed in ascending chunk order
+            const float4 *src = reinterpret_cast<const float4 *>(a.dw1part) + i;
             const long cs = live >> 2;
-            for (int c0 = 0; c0 < a.chunks; c0 += 8) {
-                float4 t[8];
+            for (int c0 = 0; c0 < a.chunks; c0 += 16) {
+                float4 t[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) t[u] = c0 + u < a.chunks ? p[(long)(c0 + u) * cs] : gmc::f4_zero();
+                for (int u = 0; u < 16; ++u) t[u] = c0 + u < a.chunks ? src[(long)(c0 + u) * cs] : gmc::f4_zero();
 #pragma unroll
-                for (int u = 0; u < 8; ++u) gmc::f4_add(g, t[u]);
+                for (int u = 0; u < 16; ++u) gmc::f4_add(g, t[u]);
             }
         }
         reinterpret_cast<float4 *>(a.grad)[i] = g;
         if (adam) {
-            float4 p = reinterpret_cast<float4 *>(a.param)[i];
-            float4 m = reinterpret_cast<float4 *>(a.m)[i];
-            float4 v = reinterpret_cast<float4 *>(a.v)[i];
             adam_elem(p.x, g.x, m.x, v.x, w1, b2, w2, step_size, bc2_sqrt, a.eps);
             adam_elem(p.y, g.y, m.y, v.y, w1, b2, w2, step_size, bc2_sqrt, a.eps);
             adam_elem(p.z, g.z, m.z, v.z, w1, b2, w2, step_size, bc2_sqrt, a.eps);
@@ -73,22 +78,40 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
             reinterpret_cast<float4 *>(a.v)[i] = v;
         }
     }
-    // tail of the flat buffer: b1 [F], W2 [F,3], b2 [3]
-    const long tail = (long)a.F + (long)a.F * 3 + 3;
+    // tail of the flat buffer: b1 [F], W2 [F,3] (column partials of the chunks, ascending order)
+    const long tail = (long)a.F + (long)a.F * 3;
     for (long j = blockIdx.x * (long)blockDim.x + threadIdx.x; j < tail; j += stride) {
+        long e = (long)j * 4 + 3;  // db1[f]
+        if (j >= a.F) { const long w = j - a.F; e = (w / 3) * 4 + w % 3; }  // dW2[f,k]
         float g = 0.f;
-        if (j < a.F) {  // db1[f]
-            for (int c = 0; c < a.chunks; ++c) g += a.colpart[((long)c * a.F + j) * 4 + 3];
-        } else if (j < (long)a.F * 4) {  // dW2[f,k]
-            const long e = j - a.F, f = e / 3, k = e % 3;
-            for (int c = 0; c < a.chunks; ++c) g += a.colpart[((long)c * a.F + f) * 4 + k];
-        } else {  // db2[k]
-            const int k = (int)(j - (long)a.F * 4);
-            for (int b = 0; b < a.B; ++b) g += a.db2part[b * 3 + k];
+        for (int c0 = 0; c0 < a.chunks; c0 += 16) {
+            float t[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) t[u] = c0 + u < a.chunks ? a.colpart[(long)(c0 + u) * a.F * 4 + e] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) g += t[u];
         }
         const long idx = nW1 + j;
         a.grad[idx] = g;
         if (adam) adam_elem(a.param[idx], g, a.m[idx], a.v[idx], w1, b2, w2, step_size, bc2_sqrt, a.eps);
+    }
+    // b2 [3]: one wave folds the per-graph partials (lane-strided sums, then a fixed xor tree)
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x < 64) {
+        float g[3] = {0.f, 0.f, 0.f};
+        for (int b = threadIdx.x; b < a.B; b += 64) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] += a.db2part[b * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) g[k] += __shfl_xor(g[k], o, GMC_WAVE);
+        if (threadIdx.x < 3) {
+            const float gk = threadIdx.x == 0 ? g[0] : threadIdx.x == 1 ? g[1] : g[2];
+            const long idx = nW1 + tail + threadIdx.x;
+            a.grad[idx] = gk;
+            if (adam) adam_elem(a.param[idx], gk, a.m[idx], a.v[idx], w1, b2, w2, step_size, bc2_sqrt, a.eps);
+        }
     }
 }
 

@@ -55,12 +55,13 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16*4] *
 // neighbours of local row l: through the 16-byte ELL row (one load, padding ids >= n hit zeroed
 // slots) when the batch carries it, else the CSR row
 template <bool ELL, typename F>
-__device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l, int n, F &&f) {
-    if (ELL) {
+__device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l, int n, bool cached, const uint4 c0,
+                                               const uint4 c1, F &&f) {
+    if (ELL) {  // cached: the row's ids are already in registers (c0, c1) - no global read
         const int W = b.ell_width;
         const uint4 *row = reinterpret_cast<const uint4 *>(b.ell + (long)(r0 + l) * W);
         for (int blk = 0; blk < W / 8; ++blk) {
-            const uint4 ids = row[blk];
+            const uint4 ids = cached ? (blk == 0 ? c0 : c1) : row[blk];
             const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
                                     ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
 #pragma unroll
@@ -86,9 +87,30 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     const bool train = a.GY2 != nullptr;
     if (a.tick && blockIdx.x == 0 && threadIdx.x == 0) *a.tick += 1;  // nobody reads it during this kernel
 
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {
-        float z = a.Z0[(long)r0 * 3 + i];
-        for (int p = 1; p < a.zparts; ++p) z += a.Z0[((long)p * a.b.R + r0) * 3 + i];
+    // The kernel is one workgroup per graph and latency-bound: request everything this thread will
+    // need from global memory now (its first row's neighbour ids, dinv, the bias), so that the three
+    // phases below pay one memory round trip instead of one each.
+    const int l0 = threadIdx.x;
+    uint4 cid0 = make_uint4(0, 0, 0, 0), cid1 = cid0;
+    float cd = 0.f;
+    if (l0 < n) {
+        cd = a.b.dinv[r0 + l0];
+        if (ELL) {
+            const uint4 *row = reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + l0) * a.b.ell_width);
+            cid0 = row[0];
+            if (a.b.ell_width > 8) cid1 = row[1];
+        }
+    }
+    const float bias0 = a.b2[0], bias1 = a.b2[1], bias2 = a.b2[2];
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {  // fold the slice-group partials, ascending
+        float z = 0.f;
+        for (int p0 = 0; p0 < a.zparts; p0 += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p0 + u < a.zparts ? a.Z0[((long)(p0 + u) * a.b.R + r0) * 3 + i] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) z += t[u];
+        }
         sA[i] = z;
     }
     if (threadIdx.x < 12) sA[3 * n + threadIdx.x] = 0.f;
@@ -99,9 +121,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float) { z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2]; });
-        const float d = a.b.dinv[r];
-        z0 = fmaf(z0, d, a.b2[0]); z1 = fmaf(z1, d, a.b2[1]); z2 = fmaf(z2, d, a.b2[2]);
+        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2]; });
+        const float d = l == l0 ? cd : a.b.dinv[r];
+        z0 = fmaf(z0, d, bias0); z1 = fmaf(z1, d, bias1); z2 = fmaf(z2, d, bias2);
         const float m = fmaxf(z0, fmaxf(z1, z2));
         const float e0 = expf(z0 - m), e1 = expf(z1 - m), e2 = expf(z2 - m);
         const float inv = 1.0f / (e0 + e1 + e2);
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         const int r = r0 + l;
         const int me = sS[l];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, cut = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float w) {
+        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float w) {
             const int sc = sS[c];  // padding slots carry class 3: no contribution
             g0 += sc == 0 ? w : 0.f; g1 += sc == 1 ? w : 0.f; g2 += sc == 2 ? w : 0.f;
             cut += (sc != me && sc != 3) ? w : 0.f;
@@ -140,7 +162,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
             const float dot = g0 * p0 + g1 * p1 + g2 * p2;
             const float z0 = p0 * (g0 - dot), z1 = p1 * (g1 - dot), z2 = p2 * (g2 - dot);
             acc[1] += z0; acc[2] += z1; acc[3] += z2;
-            const float d = a.b.dinv[r];
+            const float d = l == l0 ? cd : a.b.dinv[r];
             sA[3 * l] = z0 * d; sA[3 * l + 1] = z1 * d; sA[3 * l + 2] = z2 * d;
         }
     }
@@ -157,8 +179,8 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
-        *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, a.b.dinv[r]);
+        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
+        *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, l == l0 ? cd : a.b.dinv[r]);
     }
 }
 
