@@ -691,6 +691,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
     constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;
+    constexpr bool kRegIds = W == 8;
     int chunk, s;
     tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
     const int TF = (int)tile_floats(a.b.n_max, FS);
@@ -726,18 +727,32 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
                 if (i0 + (int)threadIdx.x < n) glds16(a.GY2 + (long)(r0 + i0 + threadIdx.x) * 4, dst);
             }
         }
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+        if constexpr (!kRegIds) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+            }
         }
     };
-    auto commit_table = [&](int n) {
+    // W == 8: a thread's rows' neighbour ids live in registers for the whole graph (both gathers):
+    // no table in LDS, no table commit and one barrier less per graph
+    uint4 idr[kRegIds ? ACC : 1];
+    auto load_ids = [&](int g) {
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+        for (int k = 0; k < (kRegIds ? ACC : 1); ++k)
+            idr[k] = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(lrow + k * kRowsPerPass, n - 1)) * W);
+    };
+    auto commit_table = [&](int n) {  // (and the zero rows the padding entries point at)
+        if constexpr (!kRegIds) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+            }
         }
         if (threadIdx.x < kPadRows * FS) {
             bufA[n * FS + threadIdx.x] = 0.f;
@@ -745,6 +760,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         }
     };
     fetch(g0);
+    if constexpr (kRegIds) load_ids(g0);
     commit_table(a.b.goff[g0 + 1] - a.b.goff[g0]);
     dma_wait();
     __syncthreads();
@@ -786,14 +802,11 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         __syncthreads();
         STAMP(2);  // barrier A
         // (2) U tile = dinv o (A @ Gs); rows past n redo row n-1 (same value to the same address)
-        if constexpr (W == 8) {
-            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+        if constexpr (kRegIds) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);
-                const uint4 cur = ids;
-                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                float4 u = gather_ids8<FS, false>(bufA, cur, nullptr, q);
+                float4 u = gather_ids8<FS, false>(bufA, idr[k], nullptr, q);
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
@@ -815,14 +828,11 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         if (g + 1 < g1) fetch(g + 1);
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
-        if constexpr (W == 8) {
-            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+        if constexpr (kRegIds) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = lrow + k * kRowsPerPass;
-                const uint4 cur = ids;
-                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                if (l < n) gmc::f4_add(acc[k], gather_ids8<FS, HAS_VAL>(bufB, cur, HAS_VAL ? wbase + (long)l * W : nullptr, q));
+                if (l < n) gmc::f4_add(acc[k], gather_ids8<FS, HAS_VAL>(bufB, idr[k], HAS_VAL ? wbase + (long)l * W : nullptr, q));
             }
         } else {
 #pragma unroll
@@ -836,9 +846,13 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         STAMP(7);  // DMA wait
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
         STAMP(8);  // barrier C
-        if (g + 1 < g1) commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
+        if (g + 1 < g1) {
+            // next graph's ids: requested now, first needed after the transform and barrier A
+            if constexpr (kRegIds) load_ids(g + 1);
+            commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
+        }
         STAMP(9);  // commit table
-        __syncthreads();
+        if constexpr (!kRegIds) __syncthreads();  // (register ids: the pad rows are ordered by barrier A)
         STAMP(10); // barrier D
     }
     STAMP_FLUSH;

@@ -122,7 +122,9 @@ SPECS_SMALL = [(100, 7, 1000), (50, 6, 1001), (64, 8, 1002), (30, 5, 1003)]
 
 
 @pytest.mark.parametrize("hidden,specs", [(16, SPECS_SMALL), (500, [(500, 7, 1000)]), (500, [(1000, 7, 2000)]),
-                                          (128, [(200, 6, 7), (300, 8, 8)])])
+                                          (128, [(200, 6, 7), (300, 8, 8)]),
+                                          # degrees 9..16: the 16-slot neighbour table; 20: no table (row kernels)
+                                          (64, [(120, 12, 11), (90, 10, 12), (60, 9, 13)]), (32, [(80, 20, 14)])])
 def test_forward_probabilities_and_partitions(pkg, hidden, specs):
     T, cfg, net, *_rest, params = model_and_params(pkg, hidden)
     ds = util.product_dataset(specs)
@@ -193,7 +195,11 @@ def flat_ref_grads(ct):
 
 
 @pytest.mark.parametrize("hidden,specs", [(16, SPECS_SMALL), (500, [(500, 7, 1000), (500, 6, 1001)]),
-                                          (500, [(1000, 7, 2000 + i) for i in range(9)])])
+                                          (500, [(1000, 7, 2000 + i) for i in range(9)]),
+                                          # the reference's default dataset name is ..._d8_12_...: degrees up to 12
+                                          (64, [(120, 12, 11), (90, 10, 12), (60, 9, 13), (200, 8, 15)]),
+                                          (500, [(300, 12, 21), (250, 11, 22), (200, 9, 23)]),
+                                          (32, [(80, 20, 14), (50, 7, 16)])])
 def test_step_gradients_match_oracle(pkg, hidden, specs):
     T, cfg, net, embed, opt, params = model_and_params(pkg, hidden)
     ds = util.product_dataset(specs)
@@ -302,7 +308,7 @@ def test_autograd_path_matches_fused_step(pkg):
     eng = net.engine()
     batch = pkg.GraphBatch([g], None, eng.device)
     _, _, fl = eng.train_fwd_bwd(batch, cfg.C)
-    assert abs(float(loss) - float(fl[0])) < 1e-3
+    assert abs(float(loss.detach()) - float(fl[0])) < 1e-3
     for k, v in eng.views(eng.grad).items():
         assert np.abs((v - auto[k]).cpu().numpy()).max() <= 1e-5 * max(1.0, float(auto[k].abs().max())), k
 
