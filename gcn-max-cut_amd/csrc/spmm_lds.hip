@@ -79,7 +79,7 @@ struct TileArgs {
     int groups;          // slice groups per graph (workgroups per graph)
     const float *W2;     // optional fused (Y o scale) @ W2
     float *Zpart;        // [groups][R][3]
-    int dbg;             // diagnostic ablation mask (GMC_LDS_DBG): 1 no stage, 2 no gather, 4 no store
+    int items_per_wg;    // fwd1: (graph, group) items per persistent workgroup
 };
 
 // block -> (graph, group): all groups of a graph on one XCD (blocks are dealt round-robin
@@ -122,12 +122,18 @@ __device__ __forceinline__ void tile_of_group_major(int b, int B, int S, int &g,
 constexpr int kPadRows = 4;
 __host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + kPadRows) * FS; }
 constexpr int kMaxSlicesPerWg = 8;
+// third LDS region (after the two tiles and the table): the larger of
+//   - the column constants (bias, W2 rows): 16 B per column - every slice of up to 1024 columns for
+//     the persistent fused forward, kMaxSlicesPerWg slices for the SpMM (8 * FS * 16 B <= that);
+//   - the per-row constants (GY2[r,:], dinv[r]) of the graph in flight in bwd1: 16 B per row
+// (bwd1's cross-wave fold area of 256 * FS B re-uses a tile buffer after its graph loop).
+size_t lds_consts(int n_max, int FS) {
+    (void)FS;
+    const size_t cols = (size_t)16 * 1024, rows = (size_t)16 * (n_max + kPadRows);
+    return cols > rows ? cols : rows;
+}
 size_t lds_bytes(int n_max, int W, int FS) {
-    // + the larger of: bias and W2 rows of up to kMaxSlicesPerWg slices (spmm / fwd1: 8 * FS * 16 B)
-    // and the per-row constants (GY2[r,:], dinv[r]) of the graph in flight (bwd1: 16 B per row; its
-    // cross-wave fold area of 256 * FS B re-uses a tile buffer after the graph loop)
-    const size_t consts = (size_t)256 * FS, rows = (size_t)16 * (n_max + kPadRows);
-    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + (consts > rows ? consts : rows);
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + lds_consts(n_max, FS);
 }
 
 // Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
@@ -504,159 +510,181 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
-    int g, grp;
-    tile_of_group_major((int)blockIdx.x, a.b.B, a.groups, g, grp);
-    const int r0 = a.b.goff[g];
-    const int n = a.b.goff[g + 1] - r0;
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
+    // Persistent workgroup: items (graph, slice group) are numbered graph-major and every workgroup
+    // owns a contiguous range of them (one workgroup per CU when the batch is large), so it walks
+    // through consecutive slices of one graph, then of the next.  The graph's table / scales are set up
+    // once per graph instead of once per item and the tile pipeline does not drain between the groups
+    // of a graph; what a group leaves behind is only its Zpart partial (same values as one
+    // workgroup per item: a graph's result does not depend on the batch it is part of).
+    const int total = a.b.B * a.groups;
+    const int it0 = (int)blockIdx.x * a.items_per_wg, it1 = min(total, it0 + a.items_per_wg);
+    if (it0 >= it1) return;
     const int per = (a.slices + a.groups - 1) / a.groups;
-    const int s_beg = grp * per, s_end = min(a.slices, s_beg + per);
-    if (s_beg >= s_end) return;
 
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
     unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
-    float *cbias = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);
-    float *cw2 = cbias + per * FS;
+    float *cbias = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [slices * FS] (all slices, once)
+    float *cw2 = cbias + a.slices * FS;                                    // [slices * FS][3]
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
-    const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
-    // W1 tile of slice s, row-major [N][ldx].  Pad columns (>= F, last slice only) load the last valid
-    // column group again: finite values, so that the masked scale below turns them into exact zeros
-    auto dma = [&](int s) {
-        dma_tile<FS, ACC>(a.X + min(s * FS + 4 * q, a.F - 4), a.x_rs, n, true, lrow, bufA);
-    };
-    dma(s_beg);
-    float zr[ACC][3] = {};
-    float sc[ACC];
+
+    {   // column constants of every slice (slices * FS <= 1024 = kThreads: one column per thread)
+        const int cc = threadIdx.x;
+        const bool c_on = cc < a.slices * FS;
+        const float cb = (c_on && a.bias && cc < a.F) ? a.bias[cc] : 0.f;
+        float cw[3] = {0.f, 0.f, 0.f};
+        if (c_on && a.W2 && cc < a.F) {
 #pragma unroll
-    for (int k = 0; k < ACC; ++k) {
-        const int l = lrow + k * kRowsPerPass;
-        sc[k] = a.scale[r0 + min(l, n - 1)];
-    }
-    // prologue: every global read is issued before the first use (one memory latency, not three)
-    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
-    uint4 pt[NT];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < 3; ++j) cw[j] = a.W2[(long)cc * 3 + j];
         }
-    }
-    const int ci = threadIdx.x, cc = s_beg * FS + ci;  // column constants of my slices (per * FS <= kThreads)
-    const bool c_on = ci < per * FS;
-    const float cb = (c_on && a.bias && cc < a.F) ? a.bias[cc] : 0.f;
-    float cw[3] = {0.f, 0.f, 0.f};
-    if (c_on && a.W2 && cc < a.F) {
+        if (c_on) {
+            cbias[cc] = cb;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) cw[j] = a.W2[(long)cc * 3 + j];
-    }
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        const int i = threadIdx.x + k * kThreads;
-        if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
-    }
-    if (c_on) {
-        cbias[ci] = cb;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) cw2[3 * ci + j] = cw[j];
-    }
-    if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
-        bufA[(long)n * FS + threadIdx.x] = 0.f;
-        bufB[(long)n * FS + threadIdx.x] = 0.f;
+            for (int j = 0; j < 3; ++j) cw2[3 * cc + j] = cw[j];
+        }
     }
 
-    dma_wait();  // table / constants / first tile
-    STAMP(11);  // prologue
-    for (int s = s_beg; s < s_end; ++s) {
-        STAMP(0);  // loop overhead / previous tail
-        // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
-        if (s > s_beg) vm_wait<ACC>();
-        STAMP(1);  // DMA wait
-        lds_barrier();  // ... for every wave; readers of the previous T0 tile are done
-        STAMP(2);  // barrier 1
-        // gather #1: T0 tile
-        if constexpr (W == 8) {
-            uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+    for (int it = it0; it < it1;) {
+        const int g = it / a.groups;
+        const int it_end = min(it1, (g + 1) * a.groups);           // my items of graph g
+        const int s_lo = (it - g * a.groups) * per, s_hi = min(a.slices, (it_end - g * a.groups) * per);
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+        // W1 tile of slice s, row-major [N][ldx].  Pad columns (>= F, last slice only) load the last
+        // valid column group again: finite values, so that the masked scale below makes exact zeros
+        auto dma = [&](int s) {
+            dma_tile<FS, ACC>(a.X + min(s * FS + 4 * q, a.F - 4), a.x_rs, n, true, lrow, bufA);
+        };
+        if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
+        // graph prologue: every global read is issued before the first use (one memory latency)
+        dma(s_lo);
+        float sc[ACC];
 #pragma unroll
-            for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                const uint4 cur = ids;
-                if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
-                const int lc = min(l, n - 1);
-                float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
-                t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
-                reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
+        for (int k = 0; k < ACC; ++k) sc[k] = a.scale[r0 + min(lrow + k * kRowsPerPass, n - 1)];
+        uint4 pt[NT];
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
             }
-        } else {
 #pragma unroll
-            for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n) {
-                    float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
-                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
-                    reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+            }
+        }
+        if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
+            bufA[(long)n * FS + threadIdx.x] = 0.f;
+            bufB[(long)n * FS + threadIdx.x] = 0.f;
+        }
+        float zr[ACC][3] = {};
+        // a slice group's Zpart partial.  Called one gather later than the group ends (after the next
+        // slice's barrier 2): by then the group's H stores have long retired, so whatever vector-memory
+        // wait the compiler attaches to this rarely-run block (spill reloads) costs nothing
+        auto flush = [&](int grp) {
+            if (a.Zpart) {
+                float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    float z0 = zr[k][0], z1 = zr[k][1], z2 = zr[k][2];
+#pragma unroll
+                    for (int o = Q / 2; o > 0; o >>= 1) {
+                        z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); z2 += __shfl_xor(z2, o, GMC_WAVE);
+                    }
+                    int l = lrow + k * kRowsPerPass;
+                    asm volatile("" : "+v"(l));  // keeps the store addresses out of the slice loop's live set
+                    if (q == 0 && l < n) {
+                        zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = z2 * sc[k];
+                    }
                 }
             }
-        }
-        STAMP(3);  // gather 1
-        lds_barrier();
-        STAMP(4);  // barrier 2
-        if (s + 1 < s_end) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
-        STAMP(5);  // DMA issue
-        // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
-        // row n-1: same value to the same address) so that the vm_wait above counts exactly
-        const int cl = (s - s_beg) * FS + 4 * q;
-        const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
-        const bool col_pad = s * FS + 4 * q >= a.F;  // slab pad columns: stored as zeros
-        float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
-        const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
-        const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
-        const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
-        // pad columns: finite tile values (see dma) * scale 0 + bias 0 = exact zeros, no per-row select
-        float scm[ACC];
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
-        auto emit = [&](int k, const float4 acc) {
-            const int l = min(lrow + k * kRowsPerPass, n - 1);
-            float4 y;
-            y.x = fmaf(acc.x, scm[k], bias.x); y.y = fmaf(acc.y, scm[k], bias.y);
-            y.z = fmaf(acc.z, scm[k], bias.z); y.w = fmaf(acc.w, scm[k], bias.w);
-            y.x = gmc::relu1(y.x); y.y = gmc::relu1(y.y); y.z = gmc::relu1(y.z); y.w = gmc::relu1(y.w);  // F.relu, :81
-            *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
-            zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
-            zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
-            zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
+            for (int k = 0; k < ACC; ++k) zr[k][0] = zr[k][1] = zr[k][2] = 0.f;
         };
-        uint4 ids2 = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
-#pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = min(lrow + k * kRowsPerPass, n - 1);
+        dma_wait();  // table / first tile
+        STAMP(11);  // prologue
+        for (int s = s_lo; s < s_hi; ++s) {
+            STAMP(0);  // loop overhead / previous tail
+            // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
+            if (s > s_lo) vm_wait<ACC>();
+            STAMP(1);  // DMA wait
+            lds_barrier();  // ... for every wave; readers of the previous T0 tile are done
+            STAMP(2);  // barrier 1
+            // gather #1: T0 tile
             if constexpr (W == 8) {
-                const uint4 cur = ids2;
-                if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                emit(k, gather_ids8<FS, false>(bufB, cur, nullptr, q));
+                uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const int l = lrow + k * kRowsPerPass;
+                    const uint4 cur = ids;
+                    if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                    // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
+                    const int lc = min(l, n - 1);
+                    float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                    reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
+                }
             } else {
-                emit(k, gather_row<FS, W, false>(bufB, nb, nullptr, l, q));
-            }
-        }
-        STAMP(6);  // gather 2
-    }
-    if (a.Zpart) {
-        float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            float z0 = zr[k][0], z1 = zr[k][1], z2 = zr[k][2];
+                for (int k = 0; k < ACC; ++k) {
+                    const int l = lrow + k * kRowsPerPass;
+                    if (l < n) {
+                        float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                        t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                        reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+                    }
+                }
+            }
+            STAMP(3);  // gather 1
+            lds_barrier();
+            STAMP(4);  // barrier 2
+            if (s > s_lo && s % per == 0) flush(s / per - 1);  // the group that ended with slice s-1
+            if (s + 1 < s_hi) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+            STAMP(5);  // DMA issue
+            // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
+            // row n-1: same value to the same address) so that the vm_wait above counts exactly
+            const int cl = s * FS + 4 * q;  // constants are indexed by absolute column
+            const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
+            const bool col_pad = s * FS + 4 * q >= a.F;  // slab pad columns: stored as zeros
+            float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
+            const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
+            const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
+            const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
+            // pad columns: finite tile values (see dma) * scale 0 + bias 0 = exact zeros, no per-row select
+            float scm[ACC];
 #pragma unroll
-            for (int o = Q / 2; o > 0; o >>= 1) {
-                z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); z2 += __shfl_xor(z2, o, GMC_WAVE);
+            for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
+            auto emit = [&](int k, const float4 acc) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                float4 y;
+                y.x = fmaf(acc.x, scm[k], bias.x); y.y = fmaf(acc.y, scm[k], bias.y);
+                y.z = fmaf(acc.z, scm[k], bias.z); y.w = fmaf(acc.w, scm[k], bias.w);
+                y.x = gmc::relu1(y.x); y.y = gmc::relu1(y.y); y.z = gmc::relu1(y.z); y.w = gmc::relu1(y.w);  // F.relu, :81
+                *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+                zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
+                zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
+                zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
+            };
+            uint4 ids2 = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                if constexpr (W == 8) {
+                    const uint4 cur = ids2;
+                    if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                    emit(k, gather_ids8<FS, false>(bufB, cur, nullptr, q));
+                } else {
+                    emit(k, gather_row<FS, W, false>(bufB, nb, nullptr, l, q));
+                }
             }
-            const int l = lrow + k * kRowsPerPass;
-            if (q == 0 && l < n) {
-                zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = z2 * sc[k];
-            }
+            STAMP(6);  // gather 2
         }
+        flush((s_hi - 1) / per);  // last group of this graph segment
+        it = it_end;
     }
     STAMP(7);  // epilogue
     STAMP_FLUSH;
@@ -1015,15 +1043,27 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
 }
 
 template <int FS, int W>
-int launch_fwd1(const TileArgs &a, size_t lds, hipStream_t st) {
+int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
     constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
-    const int grid = a.b.B * a.groups;
     if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
                                     : launch(fwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
     if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
                                     : launch(fwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
     return GMC_ERR_UNSUPPORTED;
+}
+
+// compute units of the current device (persistent kernels launch one workgroup per CU)
+int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
 }
 
 // fused layer-1 forward: H (slab layout) = relu(dinv o (A @ (dinv o (A_val @ W1[:n]))) + b1) and
@@ -1033,21 +1073,27 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
+    const int slices = (F + fs - 1) / fs, groups = gmc_lds_groups(b, F);
+    // the column constants of every slice sit in LDS: 16 B per (padded) column
+    if ((size_t)slices * fs > (size_t)kThreads || (size_t)16 * slices * fs > lds_consts(b->n_max, fs)) return GMC_ERR_UNSUPPORTED;
+    // contiguous ranges of (graph, group) items, one persistent workgroup per CU when there are enough
+    const int total = b->B * groups, cus = device_cus();
+    const int ipw = (total + cus - 1) / cus, grid = (total + ipw - 1) / ipw;
     TileArgs a{*b, W1, (long)F, (long)fs, 1, b->ell_vals != nullptr, b->dinv, b1, 1, H, (long)fs, (long)b->R * fs,
-               F, (F + fs - 1) / fs, gmc_lds_groups(b, F), W2, Zpart, 0};
+               F, slices, groups, W2, Zpart, ipw};
     const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(GMC_K_FWD1_FUSED, st);
     if (b->ell_width == 8) {
         switch (fs) {
-            case 64: return launch_fwd1<64, 8>(a, lds, st);
-            case 32: return launch_fwd1<32, 8>(a, lds, st);
-            default: return launch_fwd1<16, 8>(a, lds, st);
+            case 64: return launch_fwd1<64, 8>(a, lds, grid, st);
+            case 32: return launch_fwd1<32, 8>(a, lds, grid, st);
+            default: return launch_fwd1<16, 8>(a, lds, grid, st);
         }
     }
     switch (fs) {
-        case 64: return launch_fwd1<64, 16>(a, lds, st);
-        case 32: return launch_fwd1<32, 16>(a, lds, st);
-        default: return launch_fwd1<16, 16>(a, lds, st);
+        case 64: return launch_fwd1<64, 16>(a, lds, grid, st);
+        case 32: return launch_fwd1<32, 16>(a, lds, grid, st);
+        default: return launch_fwd1<16, 16>(a, lds, grid, st);
     }
 }
 
