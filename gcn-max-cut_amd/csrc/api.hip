@@ -10,7 +10,8 @@ int gmc_hidden_slab_tiles(int R);
 int gmc_hidden_bwd_slab_launch(const float *, const float *, const float *, const float *, float *, float *, int,
                                int, int, hipStream_t);
 int gmc_lds_slice_width(const gmc_batch *b);
-int gmc_dw1_chunks(int B, bool lds);
+int gmc_dw1_chunks(int B, bool lds, int slices);
+int gmc_lds_slices(const gmc_batch *b, int F);
 int gmc_fold_chunks_launch(const float *, float *, int, int, int, int, hipStream_t);
 bool gmc_bwd1_fits(const gmc_batch *b);
 int gmc_head_launch(const gmc_batch *, const float *, int32_t, const float *, float, float *, int32_t *, float *,
@@ -88,7 +89,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     if (training) {
         w.GY2 = take(R * 4);  // (GY2[r,0..2], dinv[r]) per row: one aligned 16 B load downstream
         size_t tiles = w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R);
-        if (w.fs && (size_t)gmc_dw1_chunks(b->B, true) > tiles) tiles = gmc_dw1_chunks(b->B, true);
+        if (w.fs && (size_t)gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, F)) > tiles) tiles = gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, F));
         w.part = take(tiles * F * 4);
         w.db2part = take((size_t)b->B * 3);
         w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
@@ -148,7 +149,7 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
     if (w.fs && fuse_enabled() && gmc_bwd1_fits(b)) {  // one pass over H: Gs and U live only in LDS
-        const int chunks = gmc_dw1_chunks(b->B, true), per = (b->B + chunks - 1) / chunks;
+        const int chunks = gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, m->F)), per = (b->B + chunks - 1) / chunks;
         int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
         if (rc) return rc;
         return gmc_finish_launch(w.dw1part, w.part, w.db2part, chunks, b->n_max, m->N, m->F, b->B, grad,

@@ -7,6 +7,7 @@
 // 8 rows in flight, graphs ascending; writes either dW1 directly (one chunk) or a
 // per-chunk partial that fold_chunks sums in chunk order.  No atomics: reproducible.
 #include "gmc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256) void fold_chunks_kernel(const float4 *part, fl
 }  // namespace
 
 bool gmc_lds_fits(const gmc_batch *b);
+int gmc_lds_slices(const gmc_batch *b, int F);
 int gmc_dw1_lds_launch(const gmc_batch *, const float *, long, int, float *, int, int, int, hipStream_t);
 
 int gmc_fold_chunks_launch(const float *scratch, float *dW1, int N, int rows, int F, int chunks, hipStream_t st) {
@@ -118,10 +120,15 @@ int gmc_fold_chunks_launch(const float *scratch, float *dW1, int N, int rows, in
 }
 
 // chunks the batch is split into for parallelism
-int gmc_dw1_chunks(int B, bool lds) {
-    if (lds) {  // (slice, chunk) workgroups, one per CU: aim at ~512 (two even rounds of 256 CUs
-                // at 32 slices) without letting the [chunks][n_max][F] partials grow large
-        int c = B < 16 ? B : 16;
+int gmc_dw1_chunks(int B, bool lds, int slices) {
+    if (lds) {  // (slice, chunk) workgroups: one round of one workgroup per CU (256 / slices chunks, at
+                // most 16 so that the [chunks][n_max][F] partials stay small); fewer, longer workgroups
+                // amortise their set-up and leave the fold fewer partials to read
+        static const int env = getenv("GMC_DW1_CHUNKS") ? atoi(getenv("GMC_DW1_CHUNKS")) : 0;  // tuning runs only
+        int cap = slices > 0 ? (256 + slices - 1) / slices : 8;
+        if (cap > 16) cap = 16;
+        if (env > 0) cap = env;
+        int c = B < cap ? B : cap;
         if (c < 1) c = 1;
         return c;
     }
@@ -132,7 +139,7 @@ int gmc_dw1_chunks(int B, bool lds) {
 
 // floats of scratch gmc_dw1_launch needs
 size_t gmc_dw1_scratch_floats(const gmc_batch *b, int N, int F, bool lds) {
-    const int chunks = gmc_dw1_chunks(b->B, lds);
+    const int chunks = gmc_dw1_chunks(b->B, lds, lds ? gmc_lds_slices(b, F) : 0);
     if (lds) return (size_t)chunks * b->n_max * F;
     return chunks > 1 ? (size_t)chunks * N * F : 0;
 }
@@ -140,7 +147,7 @@ size_t gmc_dw1_scratch_floats(const gmc_batch *b, int N, int F, bool lds) {
 int gmc_dw1_launch(const gmc_batch *b, const float *U, long ldu, float *dW1, float *scratch,
                    int N, int F, bool lds, hipStream_t st) {
     if (F % 4 || ldu % 4 || F > 1024) return GMC_ERR_ALIGN;
-    const int chunks = gmc_dw1_chunks(b->B, lds);
+    const int chunks = gmc_dw1_chunks(b->B, lds, lds ? gmc_lds_slices(b, F) : 0);
     const int per = (b->B + chunks - 1) / chunks;
     int rows = N;
     if (lds) {

@@ -986,6 +986,12 @@ bool gmc_bwd1_fits(const gmc_batch *b) { return gmc_lds_fits(b); }
 // slice groups (workgroups) per graph == number of Zpart partials of the fused W2 epilogue.
 // Fixed per model shape (independent of the batch), so a graph's result is bitwise the same
 // whatever batch it is part of.  GMC_LDS_SLICES_PER_WG overrides (tuning runs only).
+// column slices of the LDS-tiled kernels for F columns (0: graphs do not fit)
+int gmc_lds_slices(const gmc_batch *b, int F) {
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    return fs ? (F + fs - 1) / fs : 0;
+}
+
 int gmc_lds_groups(const gmc_batch *b, int F) {
     const int fs = pick_fs(b->n_max, b->ell_width);
     if (!fs) return 0;

@@ -1,0 +1,7 @@
+set -e
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do for c in 16 8; do
+GMC_DW1_CHUNKS=$c python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>>gpurun_out/ch.err | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_ms']
+print('chunks $c', round(d['value'],1), round(d['ms_per_step'],4), {a:round(b*1000,1) for a,b in k.items()})"
+done; done
