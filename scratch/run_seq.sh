@@ -1,11 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 for per in 4 2 1; do
-  echo "== slices/wg $per"
-  GMC_LDS_SLICES_PER_WG=$per python bench.py --mode sequential --graphs-per-gpu 20 --steps 20 --warmup 3 --no-cpu-baseline 2>gpurun_out/seq_$per.err | tee gpurun_out/seq_$per.json
+  GMC_LDS_SLICES_PER_WG=$per python bench.py --mode sequential --graphs-per-gpu 20 --steps 20 --warmup 3 --no-cpu-baseline 2>gpurun_out/seq_$per.err | python -c "
+import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_ms']
+print('per $per', round(d['ms_per_step'],4), 'eager', round(d['ms_per_step_eager_probed'],3), {a:round(b*1000,1) for a,b in k.items()})"
 done
-mkdir -p gpurun_out/pmc_lds
-rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -d gpurun_out/pmc_lds -o lds --output-format csv -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_lds/bench.log 2>&1
-ls gpurun_out/pmc_lds

@@ -18,10 +18,10 @@ for _ in range(3): eng.train_fwd_bwd(batch)
 torch.cuda.synchronize()
 # forward only -> stamps of fwd1 (grid 1280)
 eng.forward(batch); torch.cuda.synchronize()
-a = read(1280)
+a = read(256)
 tot = a[:, :12].sum(1).mean()
 print("fwd1 cycles per WG %.0f" % tot, {k: round(100 * a[:, i].mean() / tot, 1) for i, k in enumerate(names["fwd"])}, "epilogue %.1f prologue %.1f" % (100 * a[:, 7].mean() / tot, 100 * a[:, 11].mean() / tot))
 eng.train_fwd_bwd(batch); torch.cuda.synchronize()
-b = read(512)
+b = read(256)
 tot = b[:, :11].sum(1).mean()
 print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})

@@ -4,7 +4,7 @@ tag = sys.argv[1]  # e.g. r01c
 def short(name):
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", name)
     return m.group(1) if m else name[:60]
-stats = glob.glob(f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv")[0]
+stats = (glob.glob(f"gpurun_out/prof_{tag}/*_kernel_stats.csv") + glob.glob(f"gpurun_out/prof_{tag}/*/*_kernel_stats.csv"))[0]
 rows = [r for r in csv.DictReader(open(stats)) if "anonymous namespace" in r["Name"]]
 with open(f"profiles/r01_bench_kernel_stats.csv", "w") as f:
     w = csv.writer(f); w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us", "pct_of_gpu_time"])
@@ -13,7 +13,7 @@ with open(f"profiles/r01_bench_kernel_stats.csv", "w") as f:
                     f'{float(r["MaxNs"])/1e3:.2f}', r["Percentage"]])
 pmc = collections.defaultdict(dict)
 for ctr in ("fetch", "write"):
-    f = glob.glob(f"gpurun_out/pmc_{ctr}_{tag}/*/*_counter_collection.csv")[0]
+    f = (glob.glob(f"gpurun_out/pmc_{ctr}_{tag}/*_counter_collection.csv") + glob.glob(f"gpurun_out/pmc_{ctr}_{tag}/*/*_counter_collection.csv"))[0]
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "anonymous namespace" in r["Kernel_Name"]:
