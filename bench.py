@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--graphs-per-gpu", type=int, default=EPOCH_GRAPHS)
     ap.add_argument("--nodes", type=int, default=1000, help="nodes per graph")
     ap.add_argument("--degree", type=int, default=7)

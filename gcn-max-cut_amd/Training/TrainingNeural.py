@@ -325,6 +325,7 @@ class FusedTrainer:
         self._graph_steps = 0
         self._batches: List[GraphBatch] = []
         self._loss_slots: Optional[torch.Tensor] = None
+        self._loss_host: Optional[torch.Tensor] = None
         self._out = None
 
     def prepare(self, dataset: Dict) -> None:
@@ -347,6 +348,10 @@ class FusedTrainer:
                      torch.empty(rmax, dtype=torch.int32, device=dev))
         self._loss_slots = torch.zeros((len(self._batches), max(bmax, 1)), dtype=torch.float32, device=dev)
         self._step_loss = torch.zeros(len(self._batches), dtype=torch.float32, device=dev)
+        # pinned landing buffer of the per-graph losses: the copy is enqueued behind the epoch's
+        # kernels (inside the replayed hipGraph on one GPU), the host then waits on one event
+        self._loss_host = (torch.empty_like(self._loss_slots, device="cpu").pin_memory()
+                           if dev.type == "cuda" else None)
         self._plan_key = key
         self._graph = None
 
@@ -372,7 +377,13 @@ class FusedTrainer:
             return float(sum(self._step_loss.cpu().tolist()))   # one host sync per epoch
         # one device->host copy per epoch; the reference adds one float per optimizer step
         # (loss.item(), :388), each the sum of that step's per-graph losses
-        host = self._loss_slots.cpu().numpy()
+        if self._loss_host is not None:
+            if not self._use_graph():   # (the replayed graph ends with this copy)
+                self._loss_host.copy_(self._loss_slots, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            host = self._loss_host.numpy()
+        else:
+            host = self._loss_slots.cpu().numpy()
         total = 0.0
         for i, batch in enumerate(self._batches):
             total += float(host[i, :batch.B].sum(dtype=np.float32))
@@ -386,10 +397,12 @@ class FusedTrainer:
                 and hasattr(self.eng, "train_step")
                 and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
 
-    def _enqueue_epoch(self) -> None:
+    def _enqueue_epoch(self, with_readback: bool = False) -> None:
         eng, cfg = self.eng, self.config
         for i, batch in enumerate(self._batches):
             eng.train_step(batch, cfg.learning_rate, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+        if with_readback and self._loss_host is not None:
+            self._loss_host.copy_(self._loss_slots, non_blocking=True)
 
     def _replay_epoch(self) -> None:
         eng = self.eng
@@ -399,9 +412,10 @@ class FusedTrainer:
             graph = torch.cuda.CUDAGraph()
             before = eng.step_count
             with torch.cuda.graph(graph):
-                self._enqueue_epoch()
+                self._enqueue_epoch(with_readback=True)
             eng.step_count = before               # capture enqueued nothing
             self._graph, self._graph_steps = graph, len(self._batches)
+            self._loss_host.copy_(self._loss_slots, non_blocking=True)   # this (eager) epoch's losses
             return
         self._graph.replay()
         eng.step_count += self._graph_steps

@@ -1,4 +1,4 @@
-# same-box A/B: base library (HEAD) vs candidate (working tree), interleaved twice
+# same-box A/B: base library (HEAD~) vs candidate (working tree), interleaved twice
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
