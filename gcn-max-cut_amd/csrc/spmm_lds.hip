@@ -1061,6 +1061,10 @@ int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
 
 // compute units of the current device (persistent kernels launch one workgroup per CU)
 int device_cus() {
+    if (const char *e = getenv("GMC_DEVICE_CUS")) {  // tests: force long item ranges per workgroup
+        const int v = atoi(e);
+        if (v > 0) return v;
+    }
     static int cus = 0;
     if (!cus) {
         int dev = 0, n = 0;

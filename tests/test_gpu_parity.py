@@ -172,6 +172,29 @@ def test_batched_forward_is_bitwise_the_per_graph_forward(pkg):
                 assert float((batch.split(P)[g] - Pg).abs().max()) < 1e-6
 
 
+def test_persistent_forward_ranges_cross_graphs(pkg, monkeypatch):
+    """The fused forward hands every workgroup a contiguous range of (graph, slice group) items.
+    With 4 'CUs' a range spans several graphs of different sizes: the result must be bitwise the
+    one-item-per-workgroup result (and within tolerance of the oracle, checked elsewhere)."""
+    T, cfg, net, *_ = model_and_params(pkg, 500)
+    eng = net.engine()
+    specs = [(300, 7, 41), (120, 6, 42), (1000, 7, 43), (64, 5, 44), (500, 8, 45), (250, 7, 46), (90, 6, 47)]
+    items = list(util.product_dataset(specs).values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    monkeypatch.setenv("GMC_DEVICE_CUS", "100000")   # one item per workgroup
+    P1, S1, l1 = [t.clone() for t in eng.forward(batch, 1.0, want_loss=True)]
+    for cus in ("4", "3", "1"):
+        monkeypatch.setenv("GMC_DEVICE_CUS", cus)
+        P2, S2, l2 = eng.forward(batch, 1.0, want_loss=True)
+        assert torch.equal(P1, P2) and torch.equal(S1, S2) and torch.equal(l1, l2), cus
+    monkeypatch.setenv("GMC_DEVICE_CUS", "3")
+    eng.train_fwd_bwd(batch, 1.0)
+    g3 = eng.grad.clone()
+    monkeypatch.delenv("GMC_DEVICE_CUS")
+    eng.train_fwd_bwd(batch, 1.0)
+    assert torch.equal(g3, eng.grad)
+
+
 def test_loss_equals_minus_cut_of_argmax_partition(pkg):
     T, cfg, net, *_ = model_and_params(pkg, 64)
     ds = util.product_dataset(SPECS_SMALL + [(500, 7, 5)])
