@@ -326,6 +326,7 @@ class FusedTrainer:
         self._batches: List[GraphBatch] = []
         self._loss_slots: Optional[torch.Tensor] = None
         self._loss_host: Optional[torch.Tensor] = None
+        self._step_host: Optional[torch.Tensor] = None
         self._out = None
 
     def prepare(self, dataset: Dict) -> None:
@@ -352,6 +353,8 @@ class FusedTrainer:
         # kernels (inside the replayed hipGraph on one GPU), the host then waits on one event
         self._loss_host = (torch.empty_like(self._loss_slots, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
+        self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
+                           if dev.type == "cuda" else None)
         self._plan_key = key
         self._graph = None
 
@@ -373,8 +376,12 @@ class FusedTrainer:
                     eng.allreduce_grad()
                     self._step_loss[i:i + 1].copy_(tail)
                 eng.adam_step(cfg.learning_rate)
-        if self.world > 1:
-            return float(sum(self._step_loss.cpu().tolist()))   # one host sync per epoch
+        if self.world > 1:   # one host sync per epoch
+            if self._step_host is not None:
+                self._step_host.copy_(self._step_loss, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                return float(self._step_host.numpy().sum(dtype=np.float64))
+            return float(sum(self._step_loss.cpu().tolist()))
         # one device->host copy per epoch; the reference adds one float per optimizer step
         # (loss.item(), :388), each the sum of that step's per-graph losses
         if self._loss_host is not None:
