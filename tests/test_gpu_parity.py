@@ -172,6 +172,35 @@ def test_batched_forward_is_bitwise_the_per_graph_forward(pkg):
                 assert float((batch.split(P)[g] - Pg).abs().max()) < 1e-6
 
 
+def test_graphs_larger_than_the_lds_tiles_use_the_row_kernels(pkg):
+    """n_nodes = 1600: graphs beyond the LDS tile capacity (n > 1020) take the row-per-wave kernels;
+    same parity bar (the C oracle), mixed in one batch with a graph that would fit."""
+    from gcn_max_cut_amd.Training import TrainingNeural as T
+    cfg = T.TrainingConfig(n_nodes=1600, hidden_dim=48)
+    torch.manual_seed(1)
+    net, embed, opt = T.setup_model_and_optimizer(cfg)
+    params = util.np_params(net.state_dict())
+    specs = [(1500, 7, 61), (1100, 6, 62), (200, 8, 63)]
+    ds = util.product_dataset(specs, max_nodes=1600)
+    eng = net.engine()
+    items = list(ds.values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = eng.train_fwd_bwd(batch, 1.0)
+    ct = CO.CTrainer(params)
+    ref_loss = ct.step(util.csrs_of(ds))
+    assert np.array_equal(loss.cpu().numpy(), ref_loss)
+    ref = flat_ref_grads(ct)
+    for k, g in eng.views(eng.grad).items():
+        g, r = g.cpu().numpy().ravel(), ref[k]
+        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
+    off = 0
+    for (rp, cl, vl) in util.csrs_of(ds):
+        f = CO.forward(rp, cl, vl, params["conv1.weight"], params["conv1.bias"], params["conv2.weight"], params["conv2.bias"])
+        n = len(rp) - 1
+        assert np.abs(P[off:off + n].cpu().numpy() - f["P"]).max() < PROB_TOL
+        off += n
+
+
 def test_persistent_forward_ranges_cross_graphs(pkg, monkeypatch):
     """The fused forward hands every workgroup a contiguous range of (graph, slice group) items.
     With 4 'CUs' a range spans several graphs of different sizes: the result must be bitwise the
