@@ -130,7 +130,8 @@ int gmc_dw1_chunks(int B, bool lds, int slices) {
         if (env > 0) cap = env;
         int c = B < cap ? B : cap;
         if (c < 1) c = 1;
-        return c;
+        const int per = (B + c - 1) / c;  // graphs per chunk; no chunk may stay empty (its partials
+        return per > 0 ? (B + per - 1) / per : 1;  // would never be written but are folded)
     }
     if (B <= 4) return 1;
     const int c = (B + 7) / 8;  // ~8 graphs per wave: 1000 rows x chunks waves

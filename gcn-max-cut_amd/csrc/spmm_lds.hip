@@ -983,21 +983,33 @@ bool gmc_lds_fits(const gmc_batch *b) {
 
 bool gmc_bwd1_fits(const gmc_batch *b) { return gmc_lds_fits(b); }
 
-// slice groups (workgroups) per graph == number of Zpart partials of the fused W2 epilogue.
-// Fixed per model shape (independent of the batch), so a graph's result is bitwise the same
-// whatever batch it is part of.  GMC_LDS_SLICES_PER_WG overrides (tuning runs only).
+int device_cus(bool allow_override = true);
+
 // column slices of the LDS-tiled kernels for F columns (0: graphs do not fit)
 int gmc_lds_slices(const gmc_batch *b, int F) {
     const int fs = pick_fs(b->n_max, b->ell_width);
     return fs ? (F + fs - 1) / fs : 0;
 }
 
+// Slice groups per graph == Zpart partials of the fused W2 epilogue (one workgroup, or one item of a
+// persistent workgroup, per group).  4 slices per group when that yields at least half a workgroup
+// per CU, else 2, else 1: a single n=1000 graph gets 32 groups instead of 8, a batch of 20 n=500
+// graphs 160 instead of 80.  The choice depends on the batch size only through these three classes,
+// so results are bitwise reproducible run to run and independent of WHICH graphs share a batch;
+// between classes the W2 partials are folded in a different association (last-ulp differences).
+// GMC_LDS_SLICES_PER_WG overrides (tuning runs only).
 int gmc_lds_groups(const gmc_batch *b, int F) {
     const int fs = pick_fs(b->n_max, b->ell_width);
     if (!fs) return 0;
     const int slices = (F + fs - 1) / fs;
     static const int per_env = getenv("GMC_LDS_SLICES_PER_WG") ? atoi(getenv("GMC_LDS_SLICES_PER_WG")) : 0;
-    int per = per_env > 0 ? per_env : 4;
+    int per = 4;
+    if (per_env > 0) {
+        per = per_env;
+    } else {
+        const long want = device_cus(false) / 2;  // the hardware's CUs (the test override only re-splits items)
+        while (per > 1 && (long)b->B * ((slices + per - 1) / per) < want) per >>= 1;
+    }
     if (per > kMaxSlicesPerWg) per = kMaxSlicesPerWg;
     return (slices + per - 1) / per;
 }
@@ -1060,8 +1072,8 @@ int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
 }
 
 // compute units of the current device (persistent kernels launch one workgroup per CU)
-int device_cus() {
-    if (const char *e = getenv("GMC_DEVICE_CUS")) {  // tests: force long item ranges per workgroup
+int device_cus(bool allow_override) {
+    if (const char *e = allow_override ? getenv("GMC_DEVICE_CUS") : nullptr) {  // tests: force long item ranges
         const int v = atoi(e);
         if (v > 0) return v;
     }

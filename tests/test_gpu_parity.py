@@ -151,25 +151,47 @@ def test_forward_probabilities_and_partitions(pkg, hidden, specs):
 
 
 def test_batched_forward_is_bitwise_the_per_graph_forward(pkg):
-    """A graph's result does not depend on the batch it is part of: bitwise for batches of one
-    size class (same LDS slice width), to rounding when sizes are mixed (the fused H@W2
-    partials are then folded in a different association)."""
+    """A graph's probabilities do not depend on which graphs share its batch or where it sits in it
+    (bitwise), and are the single-graph forward exactly when the launch shape class is the same
+    (same LDS slice width and slices per group); across classes the fused H@W2 partials are folded in
+    a different association: equal to rounding."""
     T, cfg, net, *_ = model_and_params(pkg, 500)
     eng = net.engine()
-    for specs, exact in (([(1000, 7, 3000 + i) for i in range(9)], True),
-                         ([(1000, 7, 3000), (500, 6, 1), (300, 8, 2), (64, 5, 3)], False)):
-        items = list(util.product_dataset(specs).values())
-        batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
-        P, S, loss = eng.forward(batch, 1.0, want_loss=True)
-        for g, it in enumerate(items):
-            single = pkg.GraphBatch([it[0]], None, eng.device)
-            Pg, Sg, lg = eng.forward(single, 1.0, want_loss=True)
-            if exact:
-                assert torch.equal(batch.split(P)[g], Pg)
-                assert torch.equal(batch.split(S)[g], Sg)
-                assert float(loss[g]) == float(lg[0])
-            else:
-                assert float((batch.split(P)[g] - Pg).abs().max()) < 1e-6
+    big = [(1000, 7, 3000 + i) for i in range(9)]
+    items = list(util.product_dataset(big).values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = [t.clone() for t in eng.forward(batch, 1.0, want_loss=True)]
+    # same graphs, reversed order, two of them swapped for others: per-graph results unchanged
+    other = list(util.product_dataset([(1000, 7, 77), (1000, 7, 78)]).values())
+    perm = items[::-1][:7] + other
+    batch2 = pkg.GraphBatch([it[0] for it in perm], None, eng.device)
+    P2, S2, loss2 = eng.forward(batch2, 1.0, want_loss=True)
+    for j in range(7):
+        g = len(items) - 1 - j
+        assert torch.equal(batch.split(P)[g], batch2.split(P2)[j])
+        assert torch.equal(batch.split(S)[g], batch2.split(S2)[j])
+        assert float(loss[g]) == float(loss2[j])
+    # single graphs: exact with the batch's grouping forced, to rounding with their own
+    for g, it in enumerate(items[:3]):
+        single = pkg.GraphBatch([it[0]], None, eng.device)
+        Pg, Sg, lg = eng.forward(single, 1.0, want_loss=True)
+        assert float((batch.split(P)[g] - Pg).abs().max()) < 1e-6
+    # same class (4 slices per group from 16 graphs of this size on): batch of 40 == batch of 20
+    many = list(util.product_dataset([(1000, 7, 5000 + i) for i in range(40)]).values())
+    b40 = pkg.GraphBatch([it[0] for it in many], None, eng.device)
+    b20 = pkg.GraphBatch([it[0] for it in many[10:30]], None, eng.device)
+    P40 = eng.forward(b40, 1.0)[0].clone()
+    P20 = eng.forward(b20, 1.0)[0]
+    for j in range(20):
+        assert torch.equal(b40.split(P40)[10 + j], b20.split(P20)[j])
+    mixed = [(1000, 7, 3000), (500, 6, 1), (300, 8, 2), (64, 5, 3)]
+    items = list(util.product_dataset(mixed).values())
+    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    P, S, loss = eng.forward(batch, 1.0, want_loss=True)
+    for g, it in enumerate(items):
+        single = pkg.GraphBatch([it[0]], None, eng.device)
+        Pg, Sg, lg = eng.forward(single, 1.0, want_loss=True)
+        assert float((batch.split(P)[g] - Pg).abs().max()) < 1e-6
 
 
 def test_graphs_larger_than_the_lds_tiles_use_the_row_kernels(pkg):
@@ -258,6 +280,9 @@ def test_step_gradients_match_oracle(pkg, hidden, specs):
     eng = net.engine()
     items = list(ds.values())
     batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
+    eng.train_fwd_bwd(batch, 1.0)      # sizes the workspace ...
+    eng._ws.fill_(255)                 # ... which is then poisoned (all-ones bytes = NaN): nothing may be
+    eng.grad.fill_(float("nan"))       # read before it is written in the same step
     P, S, loss = eng.train_fwd_bwd(batch, 1.0)
     ct = CO.CTrainer(params)
     ref_loss = ct.step(util.csrs_of(ds))
