@@ -50,6 +50,12 @@ __device__ __forceinline__ float relu1(float x) {
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// max(x, lo) as one v_max_f32: lo = 0 is relu, lo = -inf the identity (no branch on a runtime flag)
+__device__ __forceinline__ float max1(float x, float lo) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+    return r;
+}
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_add(float4 &a, const float4 &b) {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

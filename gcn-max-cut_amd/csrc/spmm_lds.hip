@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
     const float *src0 = a.X + (SHARED ? 0L : (long)r0 * a.x_rs) + 4 * q;
 
-    dma_tile<FS, ACC>(src0 + s_beg * a.x_ss, a.x_rs, n, s_beg * FS + 4 * q < a.F, lrow, lds);
+    dma_tile<FS, ACC>(src0 + s_beg * a.x_ss - max(0, s_beg * FS + 4 * q - (a.F - 4)), a.x_rs, n, true, lrow, lds);
 
     // prologue: every global read is issued before the first use, so the workgroup pays one memory
     // latency (not one per table) before its first gather
@@ -346,6 +346,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         const int cl = (s - s_beg) * FS + 4 * q;
         const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
         const bool col_on = s * FS + 4 * q < a.F;
+        const float lo = a.relu ? 0.f : -__builtin_inff();
         float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
         float4 wa, wb, wc;
         if (EPI) {  // W2 rows of my 4 columns from LDS (zero for pad columns)
@@ -357,24 +358,25 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);
             const float4 acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            // pad columns: the tile holds finite values there (see prefetch), scale 0 and bias 0 make
+            // them exact zeros without a per-row select; relu / identity is one v_max either way
+            const float sk = (EPI && !col_on) ? 0.f : sc[k];
             float4 y;
-            y.x = fmaf(acc.x, sc[k], bias.x); y.y = fmaf(acc.y, sc[k], bias.y);
-            y.z = fmaf(acc.z, sc[k], bias.z); y.w = fmaf(acc.w, sc[k], bias.w);
-            if (a.relu) {
-                y.x = y.x > 0.f ? y.x : 0.f; y.y = y.y > 0.f ? y.y : 0.f;
-                y.z = y.z > 0.f ? y.z : 0.f; y.w = y.w > 0.f ? y.w : 0.f;
-            }
+            y.x = gmc::max1(fmaf(acc.x, sk, bias.x), lo); y.y = gmc::max1(fmaf(acc.y, sk, bias.y), lo);
+            y.z = gmc::max1(fmaf(acc.z, sk, bias.z), lo); y.w = gmc::max1(fmaf(acc.w, sk, bias.w), lo);
             if (col_on) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
             if (EPI) {
-                if (!col_on) y = gmc::f4_zero();  // pad columns of the tile may hold anything (NaN * 0)
                 zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
                 zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
                 zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
             }
         }
     };
+    // tile of slice s; pad columns (>= F, last slice) load the slice's last valid column group again,
+    // so the tile never holds stale or uninitialised (possibly non-finite) values
     auto prefetch = [&](int s, int into) {
-        dma_tile<FS, ACC>(src0 + s * a.x_ss, a.x_rs, n, s * FS + 4 * q < a.F, lrow, lds + into * TF);
+        const int back = max(0, s * FS + 4 * q - (a.F - 4));  // columns past the last valid group
+        dma_tile<FS, ACC>(src0 + s * a.x_ss - back, a.x_rs, n, true, lrow, lds + into * TF);
     };
 
     // Steady state: the DMA of slice s+1 is issued first, the LDS gather of slice s runs while it is
