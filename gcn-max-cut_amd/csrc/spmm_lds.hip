@@ -746,9 +746,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
-    auto fetch = [&](int g) {  // H tile -> bufA (DMA); neighbour table -> registers
-        const int r0 = a.b.goff[g];
-        const int n = a.b.goff[g + 1] - r0;
+    auto fetch = [&](int r0, int n) {  // H tile -> bufA (DMA); neighbour table -> registers
         dma_tile<FS, ACC>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
         {   // the graph's row constants, 16 B per row, by the same DMA path (lane i -> row i)
             const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)gyl;
@@ -769,9 +767,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     // W == 8: a thread's rows' neighbour ids live in registers for the whole graph (both gathers):
     // no table in LDS, no table commit and one barrier less per graph
     uint4 idr[kRegIds ? ACC : 1];
-    auto load_ids = [&](int g) {
-        const int r0 = a.b.goff[g];
-        const int n = a.b.goff[g + 1] - r0;
+    auto load_ids = [&](int r0, int n) {
 #pragma unroll
         for (int k = 0; k < (kRegIds ? ACC : 1); ++k)
             idr[k] = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(lrow + k * kRowsPerPass, n - 1)) * W);
@@ -789,15 +785,17 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
             bufB[n * FS + threadIdx.x] = 0.f;
         }
     };
-    fetch(g0);
-    if constexpr (kRegIds) load_ids(g0);
-    commit_table(a.b.goff[g0 + 1] - a.b.goff[g0]);
+    // graph offsets are scalar loads: each is requested one graph ahead of its first use
+    int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
+    fetch(r0, n);
+    if constexpr (kRegIds) load_ids(r0, n);
+    commit_table(n);
     dma_wait();
     __syncthreads();
     STAMP_DECL;
     for (int g = g0; g < g1; ++g) {
-        const int r0 = a.b.goff[g];
-        const int n = a.b.goff[g + 1] - r0;
+        const int r0n = r0 + n;                                        // == goff[g + 1]
+        const int nn = g + 1 < g1 ? a.b.goff[g + 2] - r0n : n;         // next graph's size (used after gather 1)
         float dv[ACC];
         STAMP(0);
         // (1) H -> Gs in place + column partials.  The row constants (GY2[r,:], dinv[r]) came with the
@@ -855,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         __syncthreads();
         STAMP(4);  // barrier B
         // (3) next graph's H tile streams into bufA while (4) gathers from bufB
-        if (g + 1 < g1) fetch(g + 1);
+        if (g + 1 < g1) fetch(r0n, nn);
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
         if constexpr (kRegIds) {
@@ -878,12 +876,13 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         STAMP(8);  // barrier C
         if (g + 1 < g1) {
             // next graph's ids: requested now, first needed after the transform and barrier A
-            if constexpr (kRegIds) load_ids(g + 1);
-            commit_table(a.b.goff[g + 2] - a.b.goff[g + 1]);
+            if constexpr (kRegIds) load_ids(r0n, nn);
+            commit_table(nn);
         }
         STAMP(9);  // commit table
         if constexpr (!kRegIds) __syncthreads();  // (register ids: the pad rows are ordered by barrier A)
         STAMP(10); // barrier D
+        r0 = r0n; n = nn;
     }
     STAMP_FLUSH;
     if (col_on) {
