@@ -98,24 +98,6 @@ __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
     }
 }
 
-// block -> (graph, group), group-major inside each XCD: every graph of the XCD runs group 0,
-// then group 1, ...  Used when the big shared operand is per GROUP (the W1 column slices of
-// the fused forward: 256 KB re-read by all graphs stays hot in the XCD's L2) rather than per
-// graph.
-__device__ __forceinline__ void tile_of_group_major(int b, int B, int S, int &g, int &s) {
-    const int per_xcd = B / 8;
-    const int full = per_xcd * 8 * S;
-    if (b < full) {
-        const int xcd = b & 7, j = b >> 3;
-        s = j / per_xcd;
-        g = (j % per_xcd) * 8 + xcd;
-    } else {
-        const int t = b - full;
-        const int rem = B - per_xcd * 8;
-        g = per_xcd * 8 + t % rem;
-        s = t / rem;
-    }
-}
 
 // LDS: two tiles [(n_max + 4)][FS] floats (rows n..n+3 = zeros: the padding targets, one per
 // bank quarter, see ell_arrange.hip), then the neighbour table [n_max][W] of 16-bit ids.
@@ -171,18 +153,6 @@ __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, boo
     }
 }
 
-// graph's neighbour table -> LDS (straight 16 B copies), zero row n of both tiles; caller syncs
-template <int FS, int W>
-__device__ __forceinline__ void load_table(const gmc_batch &b, int r0, int n, float *tile0, float *tile1,
-                                           unsigned short *nb) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(b.ell + (long)r0 * W);
-    const int total = n * (W / 8);
-    for (int i = threadIdx.x; i < total; i += kThreads) reinterpret_cast<uint4 *>(nb)[i] = src[i];
-    if (threadIdx.x < kPadRows * FS) {
-        tile0[(long)n * FS + threadIdx.x] = 0.f;
-        tile1[(long)n * FS + threadIdx.x] = 0.f;
-    }
-}
 
 // Read the eight tile rows named by eight packed u16 ids (lane's 16 B of each row).  The byte
 // address id * row_bytes + (tile + 16 q) is one v_mad_u32_u16 per row (op_sel picks the id's half
