@@ -97,10 +97,12 @@ class FusedEngine:
                 ws: Optional[torch.Tensor] = None):
         """P [R,3] (and S [R], loss [B] when ``want_loss``) - TrainingNeural.py:79-85.
         ``ws``: caller-owned scratch (kept alive for a later :meth:`backward_from_gp`)."""
-        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, False)
         P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
         S = torch.empty(batch.R, dtype=torch.int32, device=self.device) if want_loss else None
         loss = torch.empty(batch.B, dtype=torch.float32, device=self.device) if want_loss else None
+        if batch.B == 0:   # nothing to launch (empty tensors have no device pointer to hand over)
+            return P, S, loss
+        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, False)
         rc = self.lib.gmc_forward(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
                                   hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.stream())
         hip.check(rc, "gmc_forward")
@@ -109,13 +111,16 @@ class FusedEngine:
     def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None):
         """forward + loss + backward for the batch's summed loss; gradient lands in
         ``self.grad[:count]`` - TrainingNeural.py:373-385."""
-        ws, nbytes = self._workspace(batch, True)
         if out is None:
             P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
             S = torch.empty(batch.R, dtype=torch.int32, device=self.device)
             loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
         else:
             P, S, loss = out
+        if batch.B == 0:   # no graphs: zero gradient, nothing to launch
+            self.grad[:self.count].zero_()
+            return P, S, loss
+        ws, nbytes = self._workspace(batch, True)
         rc = self.lib.gmc_train_fwd_bwd(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
                                         hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad),
                                         hip.stream())
