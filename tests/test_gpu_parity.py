@@ -2,6 +2,7 @@
 seeded inputs.  Tolerances: node probabilities 1e-4 (north star), argmax partitions exact,
 loss == -cut exactly, gradients 1e-4 relative to the largest entry."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -581,3 +582,28 @@ def test_forward_with_arbitrary_dense_features(pkg):
     net.train()
     with pytest.raises(NotImplementedError):
         net(g, X.cuda())
+
+
+def test_bench_line_contract(pkg):
+    """bench.py prints ONE JSON line with the keys the driver reads (small run: 8 graphs per GPU)."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--graphs-per-gpu", "8", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * 160 / (1e3 * 8) - 1) < 1e-6
+    assert d["parity"]["argmax_equal"] and d["parity"]["max_abs_prob_diff"] <= 1e-4
