@@ -368,19 +368,29 @@ class FusedTrainer:
             eng.step_dev.fill_(eng.step_count)
             self._enqueue_epoch()
         else:
-            tail = eng.grad[eng.count:eng.count + 1]   # the step's loss rides in the gradient all-reduce
+            # the step's loss rides in the gradient all-reduce: train_fwd_bwd leaves the shard's loss sum
+            # in the slot after the gradient (GMC_MODEL_GRAD_TAIL), the all-reduce makes it the batch's
+            tail = eng.grad[eng.count:eng.count + 1]
+            last = len(self._batches) - 1
             for i, batch in enumerate(self._batches):
                 eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
                 if self.world > 1:
-                    torch.sum(self._loss_slots[i, :batch.B], dim=0, keepdim=True, out=tail)
                     eng.allreduce_grad()
-                    self._step_loss[i:i + 1].copy_(tail)
+                    if i != last:                      # the last step's slot is read in place below
+                        self._step_loss[i:i + 1].copy_(tail)
                 eng.adam_step(cfg.learning_rate)
         if self.world > 1:   # one host sync per epoch
+            if not self._batches:
+                return 0.0
             if self._step_host is not None:
-                self._step_host.copy_(self._step_loss, non_blocking=True)
+                if last == 0:   # one step per epoch: its loss goes from the gradient's tail slot to the host
+                    self._step_host.copy_(tail, non_blocking=True)
+                else:
+                    self._step_loss[last:last + 1].copy_(tail)
+                    self._step_host.copy_(self._step_loss, non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 return float(self._step_host.numpy().sum(dtype=np.float64))
+            self._step_loss[last:last + 1].copy_(tail)
             return float(sum(self._step_loss.cpu().tolist()))
         # one device->host copy per epoch; the reference adds one float per optimizer step
         # (loss.item(), :388), each the sum of that step's per-graph losses

@@ -17,7 +17,8 @@ bool gmc_bwd1_fits(const gmc_batch *b);
 int gmc_head_launch(const gmc_batch *, const float *, int32_t, const float *, float, float *, int32_t *, float *,
                     float *, float *, int *, hipStream_t);
 int gmc_finish_launch(const float *, const float *, const float *, int, int, int, int, int, float *, float *, float *,
-                      float *, double, double, double, double, int *, hipStream_t);
+                      float *, double, double, double, double, int *, const float *, hipStream_t);
+int gmc_loss_tail_launch(const float *, int, float *, hipStream_t);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
                         hipStream_t);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
@@ -143,8 +144,9 @@ struct AdamFuse {  // optional Adam fused into the gradient fold (single GPU)
     int *step_counter = nullptr;
 };
 
+// loss_tail: per-graph losses whose sum goes to the slot after the gradient (GMC_MODEL_GRAD_TAIL), or nullptr
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
-                  hipStream_t st, const AdamFuse *af = nullptr) {
+                  hipStream_t st, const AdamFuse *af = nullptr, const float *loss_tail = nullptr) {
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
@@ -155,7 +157,7 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
         return gmc_finish_launch(w.dw1part, w.part, w.db2part, chunks, b->n_max, m->N, m->F, b->B, grad,
                                  af ? af->param : nullptr, af ? af->m : nullptr, af ? af->v : nullptr,
                                  af ? af->lr : 0, af ? af->beta1 : 0, af ? af->beta2 : 0, af ? af->eps : 0,
-                                 af ? af->step_counter : nullptr, st);
+                                 af ? af->step_counter : nullptr, loss_tail, st);
     }
     if (af) return GMC_ERR_UNSUPPORTED;  // the fused Adam rides on the fused backward
     int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, m->W2, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
@@ -167,7 +169,9 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     // conv1 backward aggregation:  U = dinv o (A @ Gs)
     rc = aggregate(b, w, Gs, U, m->F, nullptr, 0, nullptr, nullptr, GMC_K_AGG_BWD, st);
     if (rc) return rc;
-    return gmc_dw1_launch(b, U, w.ld, dW1, w.dw1part, m->N, m->F, w.fs != 0, st);
+    rc = gmc_dw1_launch(b, U, w.ld, dW1, w.dw1part, m->N, m->F, w.fs != 0, st);
+    if (rc || !loss_tail) return rc;
+    return gmc_loss_tail_launch(loss_tail, b->B, db2 + 3, st);
 }
 
 }  // namespace
@@ -281,15 +285,17 @@ extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model,
     Workspace w = carve(batch, model, 1, workspace);
     if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool tail = (model->flags & GMC_MODEL_GRAD_TAIL) != 0;
+    if (tail && !loss) return GMC_ERR_NULL;
     if (batch->R == 0) {
-        const size_t n = (size_t)model->N * model->F + model->F + (size_t)model->F * 3 + 3;
+        const size_t n = (size_t)model->N * model->F + model->F + (size_t)model->F * 3 + 3 + (tail ? 1 : 0);
         return (int)hipMemsetAsync(grad, 0, n * sizeof(float), st);
     }
     rc = forward_body(batch, model, w, st);
     if (rc) return rc;
     rc = gmc_head_f32(batch, w.Z0, w.zparts, model->b2, C, P, S, loss, w.GY2, w.db2part, stream);
     if (rc) return rc;
-    return backward_body(batch, model, w, grad, st);
+    return backward_body(batch, model, w, grad, st, nullptr, tail ? loss : nullptr);
 }
 
 int gmc_adam_devstep_f32(float *, const float *, float *, float *, int64_t, double, double, double, double, int32_t *,

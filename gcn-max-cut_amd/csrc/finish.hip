@@ -23,6 +23,7 @@ struct FinishArgs {
     double lr, beta1, beta2;
     float eps;
     const int *step_counter;  // device; already advanced by this step's head launch: the update uses it as is
+    const float *loss;        // [B] per-graph losses, or nullptr: their sum goes to grad[count] (GMC_MODEL_GRAD_TAIL)
 };
 
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float w1, float b2, float w2,
@@ -112,17 +113,39 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
             a.grad[idx] = gk;
             if (adam) adam_elem(a.param[idx], gk, a.m[idx], a.v[idx], w1, b2, w2, step_size, bc2_sqrt, a.eps);
         }
+        if (a.loss) {  // the batch's loss sum rides in the slot after the gradient (same fixed order)
+            float ls = 0.f;
+            for (int b = threadIdx.x; b < a.B; b += 64) ls += a.loss[b];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, GMC_WAVE);
+            if (threadIdx.x == 0) a.grad[nW1 + tail + 3] = ls;
+        }
     }
+}
+
+__global__ __launch_bounds__(64) void loss_tail_kernel(const float *loss, int B, float *slot) {
+    float ls = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) ls += loss[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, GMC_WAVE);
+    if (threadIdx.x == 0) *slot = ls;
 }
 
 }  // namespace
 
+// sum of the per-graph losses into one slot (same order as the fused fold uses)
+int gmc_loss_tail_launch(const float *loss, int B, float *slot, hipStream_t st) {
+    hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(64), 0, st, loss, B, slot);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
 // param == nullptr -> gradients only.  *step_counter (device) must already hold this step's number.
 int gmc_finish_launch(const float *dw1part, const float *colpart, const float *db2part, int chunks, int n_max,
                       int N, int F, int B, float *grad, float *param, float *m, float *v, double lr, double beta1,
-                      double beta2, double eps, int *step_counter, hipStream_t st) {
+                      double beta2, double eps, int *step_counter, const float *loss_for_tail, hipStream_t st) {
     FinishArgs a{dw1part, colpart, db2part, chunks, n_max, N, F, B, grad, param, m, v, lr, beta1, beta2, (float)eps,
-                 step_counter};
+                 step_counter, loss_for_tail};
     const long n4 = (long)N * F / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;

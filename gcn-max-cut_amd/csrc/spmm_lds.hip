@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
 #pragma unroll
     for (int k = 0; k < ACC; ++k) {
         const int l = lrow + k * kRowsPerPass;
-        sc[k] = (a.scale && l < n) ? a.scale[r0 + l] : 1.0f;
+        sc[k] = a.scale ? a.scale[r0 + min(l, n - 1)] : 1.0f;  // rows past n redo row n-1 with ITS scale
     }
     constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
     uint4 pt[NT];

@@ -60,7 +60,7 @@ class FusedEngine:
 
     def _refresh_model(self) -> None:
         v = self.views()
-        self._model = hip.GmcModel(N=self.N, F=self.F, K=self.K, reserved=0,
+        self._model = hip.GmcModel(N=self.N, F=self.F, K=self.K, flags=hip.MODEL_GRAD_TAIL,
                                    W1=hip.ptr(v["conv1.weight"]), b1=hip.ptr(v["conv1.bias"]),
                                    W2=hip.ptr(v["conv2.weight"]), b2=hip.ptr(v["conv2.bias"]))
 

@@ -23,6 +23,7 @@ SYMBOLS = (
 )
 
 MAX_GRAPH_NODES = 4096
+MODEL_GRAD_TAIL = 1   # gmc_model.flags: grad has a tail slot that receives the batch's loss sum
 
 
 class HipExtensionError(RuntimeError):
@@ -41,7 +42,7 @@ class GmcBatch(C.Structure):
 
 class GmcModel(C.Structure):
     _fields_ = [
-        ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("reserved", C.c_int32),
+        ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
     ]
 

@@ -74,9 +74,15 @@ typedef struct gmc_batch {
 /* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):
  * conv1.weight [N,F], conv1.bias [F], conv2.weight [F,K], conv2.bias [K]. */
 typedef struct gmc_model {
-    int32_t N, F, K, reserved;
+    int32_t N, F, K;
+    int32_t flags; /* GMC_MODEL_* bits, 0 by default */
     const float *W1, *b1, *W2, *b2;
 } gmc_model;
+/* gmc_train_fwd_bwd: grad has ONE more float after the N*F + F + F*3 + 3 gradient entries and
+ * receives the sum of the batch's per-graph losses there (loss must be non-NULL).  Lets a
+ * data-parallel caller carry the step's loss (TrainingNeural.py:387-388) through the gradient
+ * all-reduce instead of a second collective. */
+#define GMC_MODEL_GRAD_TAIL 1
 
 int gmc_version(void);
 const char *gmc_error_string(int code);

@@ -55,6 +55,7 @@ class OracleEngine:
                 a += d
             out[2][i] = loss
         self.grad[:self.count] = torch.from_numpy(np.concatenate([x.ravel() for x in g]))
+        self.grad[self.count] = float(np.sum(np.asarray([out[2][i] for i in range(batch.B)], np.float32)))  # GMC_MODEL_GRAD_TAIL
 
     def allreduce_grad(self):
         if dist.is_initialized() and dist.get_world_size() > 1:
