@@ -646,3 +646,4 @@ def test_bench_line_contract(pkg):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * 160 / (1e3 * 8) - 1) < 1e-6
     assert d["parity"]["argmax_equal"] and d["parity"]["max_abs_prob_diff"] <= 1e-4
+    assert d["parity"]["max_abs_prob_diff_one_kernel_per_op"] <= 1e-4
