@@ -363,10 +363,13 @@ def test_step_gradients_match_torch_autograd_oracle(pkg):
         assert np.abs(g.cpu().numpy() - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
 
 
-def test_weighted_edges_and_loss_scale(pkg):
+@pytest.mark.parametrize("fuse,specs", [(1, [(80, 7, 21), (40, 6, 22)]), (0, [(80, 7, 21), (40, 6, 22)]),
+                                        (1, [(600, 7, 23), (90, 11, 24)]), (0, [(600, 7, 23), (90, 11, 24)])])
+def test_weighted_edges_and_loss_scale(pkg, fuse, specs):
+    """Non-unit edge weights (the `vals` / `ell_vals` variants of every kernel), C != 1, in the fused
+    default and in the one-kernel-per-operation sequence."""
     T, cfg, net, embed, opt, params = model_and_params(pkg, 32)
     from gcn_max_cut_amd.DataGenerator import graphExtender as GE
-    specs = [(80, 7, 21), (40, 6, 22)]
     graphs, terms = util.weighted_copy(specs)
     ds = GE.process_graphs_from_folder(graphs, terms, 1000)
     eng = net.engine()
@@ -374,7 +377,12 @@ def test_weighted_edges_and_loss_scale(pkg):
     vals = [it[0].edge_values(it[1]) for it in items]
     assert all(v is not None for v in vals)
     batch = pkg.GraphBatch([it[0] for it in items], vals, eng.device)
-    P, S, loss = eng.train_fwd_bwd(batch, 2.5)
+    lib = pkg.hip.load()
+    prev = lib.gmc_set_fuse(fuse)
+    try:
+        P, S, loss = eng.train_fwd_bwd(batch, 2.5)
+    finally:
+        lib.gmc_set_fuse(prev)
     ct = CO.CTrainer(params, Cc=2.5)
     ref_loss = ct.step(util.csrs_of(ds))
     np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, rtol=1e-6)
