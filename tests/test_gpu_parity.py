@@ -324,7 +324,9 @@ def flat_ref_grads(ct):
                                           # the reference's default dataset name is ..._d8_12_...: degrees up to 12
                                           (64, [(120, 12, 11), (90, 10, 12), (60, 9, 13), (200, 8, 15)]),
                                           (500, [(300, 12, 21), (250, 11, 22), (200, 9, 23)]),
-                                          (32, [(80, 20, 14), (50, 7, 16)])])
+                                          (32, [(80, 20, 14), (50, 7, 16)]),
+                                          # 8 rows per thread (see test_one_kernel_per_operation_sequence_matches_oracle)
+                                          (128, [(530, 7, 31), (520, 6, 32)]), (256, [(270, 7, 33), (262, 8, 34)])])
 def test_step_gradients_match_oracle(pkg, hidden, specs):
     T, cfg, net, embed, opt, params = model_and_params(pkg, hidden)
     ds = util.product_dataset(specs)
@@ -470,7 +472,9 @@ def test_error_behaviour(pkg):
 
 
 @pytest.mark.parametrize("hidden,specs", [(16, SPECS_SMALL), (500, [(1000, 7, 5), (960, 7, 6), (500, 6, 8)]),
-                                          (64, [(120, 12, 11), (90, 10, 12)])])
+                                          (64, [(120, 12, 11), (90, 10, 12)]),
+                                          # 8 rows per thread: 32-column tiles for 512 < n <= 538, 64-column for 256 < n <= 275
+                                          (128, [(530, 7, 31), (520, 6, 32)]), (256, [(270, 7, 33), (262, 8, 34)])])
 def test_one_kernel_per_operation_sequence_matches_oracle(pkg, hidden, specs):
     """gmc_set_fuse(0): the stand-alone LDS SpMM / hidden-backward / dW1 kernels (the sequence whose
     SpMM bench.py's `roofline` times) against the C oracle, same bar as the fused default.
