@@ -416,10 +416,13 @@ def test_fused_adam_matches_torch_adam(pkg):
     np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-9)
 
 
-def test_sequential_training_follows_oracle(pkg):
-    """Three epochs of the reference schedule (one Adam step per graph)."""
+@pytest.mark.parametrize("specs", [SPECS_SMALL, [(60, 20, 51), (100, 7, 52), (40, 12, 53)]])
+def test_sequential_training_follows_oracle(pkg, specs):
+    """Three epochs of the reference schedule (one Adam step per graph), replayed as a hipGraph;
+    the second dataset mixes a degree-20 graph (row kernels, stand-alone Adam inside the captured
+    step) with 8- and 16-slot ones."""
     T, cfg, net, embed, opt, params = model_and_params(pkg, 16)
-    ds = util.product_dataset(SPECS_SMALL)
+    ds = util.product_dataset(specs)
     ct = CO.CTrainer(params, lr=cfg.learning_rate)
     csrs = util.csrs_of(ds)
     for epoch in range(3):
