@@ -434,6 +434,38 @@ def test_sequential_training_follows_oracle(pkg, specs):
         assert np.abs(v.cpu().numpy() - after[k]).max() < 5e-3, k  # a few +-lr Adam steps
 
 
+def test_data_parallel_step_sequence_equals_the_fused_step(pkg):
+    """The step a data-parallel rank runs (train_fwd_bwd -> [all-reduce] -> stand-alone Adam, loss in
+    the gradient's tail slot) against the single-GPU fused step (fold + Adam in one sweep, replayed as
+    a hipGraph): same parameters after a few epochs, same epoch losses."""
+    import copy
+
+    class WithoutFusedStep:          # an engine that offers only what the N > 1 branch uses
+        def __init__(self, eng):
+            self._eng = eng
+
+        def __getattr__(self, name):
+            if name == "train_step":
+                raise AttributeError(name)
+            return getattr(self._eng, name)
+
+    specs = [(1000, 7, 81), (640, 6, 82), (300, 8, 83), (90, 11, 84)]
+    ds = util.product_dataset(specs)
+    runs = []
+    for variant in ("fused", "dp-sequence"):
+        T, cfg, net, embed, opt, params = model_and_params(pkg, 64, seed=5)
+        eng = net.engine()
+        tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=2,
+                            engine=eng if variant == "fused" else WithoutFusedStep(eng))
+        losses = [tr.epoch(ds) for _ in range(4)]
+        assert (tr._graph is not None) == (variant == "fused")
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, int(eng.step_count)))
+    (la, pa, sa), (lb, pb, sb) = runs
+    assert sa == sb == 8 and la == lb
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) < 1e-6, k
+
+
 def test_autograd_path_matches_fused_step(pkg):
     """net(g, A) -> reference-style helper chain -> .backward() uses the HIP backward."""
     T, cfg, net, embed, opt, params = model_and_params(pkg, 32)
