@@ -221,7 +221,7 @@ def extend_matrix_torch(matrix, N, torch_dtype=None, torch_device=None):
     size = matrix.shape[0]
     if N < size:
         raise ValueError("N should be greater than or equal to the original matrix size.")
-    out = torch.zeros(size, N, dtype=matrix.dtype, device=matrix.device)
+    out = torch.zeros(size, N, device=matrix.device)  # default dtype whatever the input's (as the reference)
     out[:size, :size] = matrix
     if torch_dtype is not None:
         out = out.type(torch_dtype)

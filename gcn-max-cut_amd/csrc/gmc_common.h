@@ -56,6 +56,15 @@ __device__ __forceinline__ float max1(float x, float lo) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
     return r;
 }
+// Packed fp32 (v_pk_add/mul/fma_f32: two floats per lane in ONE 4-cycle VALU slot).  The LDS-tiled
+// kernels are instruction-issue bound, so their per-row arithmetic is written on 2-vectors explicitly
+// rather than left to the SLP vectoriser (which scalarised gather #2 of the fused forward).
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v2f splat2(float s) { return (v2f)(s); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v4f f4v(const float4 &a) { return (v4f){a.x, a.y, a.z, a.w}; }
+__device__ __forceinline__ float4 v4f_f4(const v4f &a) { return make_float4(a.x, a.y, a.z, a.w); }
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_add(float4 &a, const float4 &b) {
     a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

@@ -58,9 +58,27 @@ extern "C" int gmc_debug_read_stamps(unsigned long long *out, int n) {
 #define STAMP_FLUSH
 #endif
 
+// Diagnostic builds only (`make variant NAME=ablN DEFS=-DGMC_ABLATE=N`, scratch/run_ablate.sh): remove
+// ONE component of the fused kernels' tile loop (results are then wrong by construction) to read off
+// what that component costs in place.  The production library compiles with GMC_ABLATE == 0.
+//   1 tile DMA after the first   2 global stores of the loop   3 fused W2 / column-partial math
+//   4 LDS reads of gather #2     5 LDS reads of gather #1      6 workgroup barriers of the loop
+//   7 bwd1: the H -> Gs transform
+#ifndef GMC_ABLATE
+#define GMC_ABLATE 0
+#endif
+#define ABL(n) (GMC_ABLATE == (n))
+
 namespace {
 
-constexpr int kThreads = 1024;
+// threads per workgroup of every kernel in this file; GMC_LDS_THREADS=512 builds the tuning variant
+// (two co-resident workgroups per CU when their LDS fits) - never the shipped library
+#ifndef GMC_LDS_THREADS
+#define GMC_LDS_THREADS 1024
+#endif
+constexpr int kThreads = GMC_LDS_THREADS;
+// 4 waves per SIMD either way (1 x 1024 or 2 x 512 threads per CU): 128 VGPRs per lane
+#define GMC_LDS_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
 struct TileArgs {
     gmc_batch b;
@@ -140,6 +158,15 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 // workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
 // for every global store of the wave to be acknowledged - what the tile loops must not do.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the barriers inside the fused kernels' tile loops (removable in the GMC_ABLATE == 6 diagnostic build)
+__device__ __forceinline__ void loop_barrier() {
+    if (ABL(6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else lds_barrier();
+}
+__device__ __forceinline__ void loop_syncthreads() {
+    if (ABL(6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
 
 template <int FS, int ACC>
 __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
@@ -230,6 +257,21 @@ __device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids
     return acc;
 }
 
+// gather_ids8 for unit weights with the sum written on 2-vectors: 14 v_pk_add_f32 per row wherever it
+// is inlined (left to the SLP vectoriser, gather #2 of the fused forward came out as 28 v_add_f32).
+template <int FS>
+__device__ __forceinline__ gmc::v4f gather_ids8_pk(const float *tile, const uint4 ids, int q) {
+    float4 x[8];
+    read8(tile, q, FS * 4, ids, x);
+    gmc::v2f lo = {x[7].x, x[7].y}, hi = {x[7].z, x[7].w};  // from the last read back: one wait per row
+#pragma unroll
+    for (int u = 6; u >= 0; --u) {
+        lo += (gmc::v2f){x[u].x, x[u].y};
+        hi += (gmc::v2f){x[u].z, x[u].w};
+    }
+    return (gmc::v4f){lo.x, lo.y, hi.x, hi.y};
+}
+
 // ACC = rows per thread (ACC * rows-per-pass >= n_max).
 //
 // Slice loop, software-pipelined so that no wait ever covers a freshly issued memory op
@@ -239,7 +281,7 @@ __device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids
 //   write slice s+1 to the other LDS buffer  ->  barrier.
 // SHARED: the source is one table shared by every graph (W1 for the layer-1 feature transform)
 template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED>
-__global__ __launch_bounds__(kThreads) void spmm_lds_kernel(TileArgs a) {
+__global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
@@ -393,7 +435,7 @@ struct Dw1TileArgs {
 };
 
 template <int FS, int W, int ACC, bool HAS_VAL>
-__global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
+__global__ GMC_LDS_BOUNDS void dw1_lds_kernel(Dw1TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
@@ -477,7 +519,7 @@ __global__ __launch_bounds__(kThreads) void dw1_lds_kernel(Dw1TileArgs a) {
 // (H o dinv) @ W2 (:83) accumulated in registers.  T0 never exists in HBM: the forward of layer 1
 // writes H once and reads only W1 (from L2) and the neighbour table.
 template <int FS, int W, int ACC, bool HAS_VAL>
-__global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
+__global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -497,24 +539,19 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
     unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
-    float *cbias = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [slices * FS] (all slices, once)
-    float *cw2 = cbias + a.slices * FS;                                    // [slices * FS][3]
+    // column constants of every slice, once per workgroup: [slices * FS] x (W2[c,0..2], b1[c])
+    float4 *cst = reinterpret_cast<float4 *>(nb + (size_t)a.b.n_max * W);
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
 
-    {   // column constants of every slice (slices * FS <= 1024 = kThreads: one column per thread)
+    {   // (slices * FS <= 1024 = kThreads: one column per thread; pad columns hold zeros)
         const int cc = threadIdx.x;
         const bool c_on = cc < a.slices * FS;
-        const float cb = (c_on && a.bias && cc < a.F) ? a.bias[cc] : 0.f;
-        float cw[3] = {0.f, 0.f, 0.f};
-        if (c_on && a.W2 && cc < a.F) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) cw[j] = a.W2[(long)cc * 3 + j];
+        float4 c = gmc::f4_zero();
+        if (c_on && cc < a.F) {
+            if (a.W2) { c.x = a.W2[(long)cc * 3]; c.y = a.W2[(long)cc * 3 + 1]; c.z = a.W2[(long)cc * 3 + 2]; }
+            if (a.bias) c.w = a.bias[cc];
         }
-        if (c_on) {
-            cbias[cc] = cb;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) cw2[3 * cc + j] = cw[j];
-        }
+        if (c_on) cst[cc] = c;
     }
 
     for (int it = it0; it < it1;) {
@@ -553,7 +590,10 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
             bufA[(long)n * FS + threadIdx.x] = 0.f;
             bufB[(long)n * FS + threadIdx.x] = 0.f;
         }
-        float zr[ACC][3] = {};
+        gmc::v2f z01[ACC];  // (Z[r,0], Z[r,1]) partial of my 4 columns, per row
+        float z2[ACC];      //  Z[r,2]
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) { z01[k] = gmc::splat2(0.f); z2[k] = 0.f; }
         // a slice group's Zpart partial.  Called one gather later than the group ends (after the next
         // slice's barrier 2): by then the group's H stores have long retired, so whatever vector-memory
         // wait the compiler attaches to this rarely-run block (spill reloads) costs nothing
@@ -562,29 +602,29 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                 float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
 #pragma unroll
                 for (int k = 0; k < ACC; ++k) {
-                    float z0 = zr[k][0], z1 = zr[k][1], z2 = zr[k][2];
+                    float z0 = z01[k].x, z1 = z01[k].y, zz = z2[k];
 #pragma unroll
                     for (int o = Q / 2; o > 0; o >>= 1) {
-                        z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); z2 += __shfl_xor(z2, o, GMC_WAVE);
+                        z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); zz += __shfl_xor(zz, o, GMC_WAVE);
                     }
                     int l = lrow + k * kRowsPerPass;
                     asm volatile("" : "+v"(l));  // keeps the store addresses out of the slice loop's live set
                     if (q == 0 && l < n) {
-                        zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = z2 * sc[k];
+                        zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = zz * sc[k];
                     }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < ACC; ++k) zr[k][0] = zr[k][1] = zr[k][2] = 0.f;
+            for (int k = 0; k < ACC; ++k) { z01[k] = gmc::splat2(0.f); z2[k] = 0.f; }
         };
         dma_wait();  // table / first tile
         STAMP(11);  // prologue
         for (int s = s_lo; s < s_hi; ++s) {
             STAMP(0);  // loop overhead / previous tail
             // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
-            if (s > s_lo) vm_wait<ACC>();
+            if (s > s_lo && !ABL(1) && !ABL(2)) vm_wait<ACC>();
             STAMP(1);  // DMA wait
-            lds_barrier();  // ... for every wave; readers of the previous T0 tile are done
+            loop_barrier();  // ... for every wave; readers of the previous T0 tile are done
             STAMP(2);  // barrier 1
             // gather #1: T0 tile
             if constexpr (W == 8) {
@@ -596,7 +636,8 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                     if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
                     // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
                     const int lc = min(l, n - 1);
-                    float4 t = gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                    float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
+                                      : gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -612,34 +653,39 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                 }
             }
             STAMP(3);  // gather 1
-            lds_barrier();
+            loop_barrier();
             STAMP(4);  // barrier 2
             if (s > s_lo && s % per == 0) flush(s / per - 1);  // the group that ended with slice s-1
-            if (s + 1 < s_hi) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+            if (s + 1 < s_hi && !ABL(1)) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
             STAMP(5);  // DMA issue
             // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
             // row n-1: same value to the same address) so that the vm_wait above counts exactly
-            const int cl = s * FS + 4 * q;  // constants are indexed by absolute column
-            const float4 bias = *reinterpret_cast<const float4 *>(cbias + cl);
+            // my 4 columns' constants (indexed by absolute column): W2 rows as (w0,w1) pairs + w2, bias pairs
+            const float4 c0 = cst[s * FS + 4 * q], c1 = cst[s * FS + 4 * q + 1], c2 = cst[s * FS + 4 * q + 2],
+                         c3 = cst[s * FS + 4 * q + 3];
+            const gmc::v2f w01[4] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}, {c3.x, c3.y}};
+            const float w2c[4] = {c0.z, c1.z, c2.z, c3.z};
+            const gmc::v2f blo = {c0.w, c1.w}, bhi = {c2.w, c3.w};
             const bool col_pad = s * FS + 4 * q >= a.F;  // slab pad columns: stored as zeros
             float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
-            const float4 wa = *reinterpret_cast<const float4 *>(cw2 + 3 * cl);
-            const float4 wb = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 4);
-            const float4 wc = *reinterpret_cast<const float4 *>(cw2 + 3 * cl + 8);
             // pad columns: finite tile values (see dma) * scale 0 + bias 0 = exact zeros, no per-row select
             float scm[ACC];
 #pragma unroll
             for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
-            auto emit = [&](int k, const float4 acc) {
+            auto emit = [&](int k, const gmc::v4f acc) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);
+                const gmc::v2f s2 = gmc::splat2(scm[k]);
+                const gmc::v2f ylo = gmc::pk_fma((gmc::v2f){acc.x, acc.y}, s2, blo);
+                const gmc::v2f yhi = gmc::pk_fma((gmc::v2f){acc.z, acc.w}, s2, bhi);
                 float4 y;
-                y.x = fmaf(acc.x, scm[k], bias.x); y.y = fmaf(acc.y, scm[k], bias.y);
-                y.z = fmaf(acc.z, scm[k], bias.z); y.w = fmaf(acc.w, scm[k], bias.w);
-                y.x = gmc::relu1(y.x); y.y = gmc::relu1(y.y); y.z = gmc::relu1(y.z); y.w = gmc::relu1(y.w);  // F.relu, :81
-                *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
-                zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
-                zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
-                zr[k][2] += y.x * wa.z + y.y * wb.y + y.z * wc.x + y.w * wc.w;
+                y.x = gmc::relu1(ylo.x); y.y = gmc::relu1(ylo.y); y.z = gmc::relu1(yhi.x); y.w = gmc::relu1(yhi.y);  // F.relu, :81
+                if (!ABL(2)) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+                if (ABL(3)) { z2[k] += y.x + y.y + y.z + y.w; return; }
+                // (H o dinv) @ W2 for my columns (:83; dinv applied at the flush): 4 packed + 4 scalar FMAs
+                z01[k] = gmc::pk_fma(gmc::splat2(y.x), w01[0], z01[k]); z2[k] = fmaf(y.x, w2c[0], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.y), w01[1], z01[k]); z2[k] = fmaf(y.y, w2c[1], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.z), w01[2], z01[k]); z2[k] = fmaf(y.z, w2c[2], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.w), w01[3], z01[k]); z2[k] = fmaf(y.w, w2c[3], z2[k]);
             };
             uint4 ids2 = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
 #pragma unroll
@@ -648,9 +694,9 @@ __global__ __launch_bounds__(kThreads) void fwd1_lds_kernel(TileArgs a) {
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                    emit(k, gather_ids8<FS, false>(bufB, cur, nullptr, q));
+                    emit(k, ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS>(bufB, cur, q));
                 } else {
-                    emit(k, gather_row<FS, W, false>(bufB, nb, nullptr, l, q));
+                    emit(k, gmc::f4v(gather_row<FS, W, false>(bufB, nb, nullptr, l, q)));
                 }
             }
             STAMP(6);  // gather 2
@@ -686,7 +732,7 @@ struct Bwd1Args {
 };
 
 template <int FS, int W, int ACC, bool HAS_VAL>
-__global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
+__global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
@@ -703,16 +749,26 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     const int f0 = s * FS + 4 * q;
     const bool col_on = f0 < a.F;
     const long slab = (long)s * a.b.R * FS;
-    float w2[4][3];
+    // my 4 columns as two pairs p = (f0+2p, f0+2p+1): W2 rows, dW2 / db1 partials - all on 2-vectors
+    // (v_pk_fma_f32), the transform is VALU work on every element of H
+    gmc::v2f w2p[2][3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) w2[j][k] = col_on ? a.W2[(long)(f0 + j) * 3 + k] : 0.f;
-    float4 acc[ACC];
-    float colp[16] = {};  // [j][0..2] dW2, [j][3] db1 for my 4 columns
+        for (int k = 0; k < 3; ++k)
+            w2p[p][k] = col_on ? (gmc::v2f){a.W2[(long)(f0 + 2 * p) * 3 + k], a.W2[(long)(f0 + 2 * p + 1) * 3 + k]}
+                               : gmc::splat2(0.f);
+    gmc::v4f acc[ACC];
+    gmc::v2f cdw2[3][2], cdb1[2];  // dW2[pair, k] and db1[pair] partials of my rows
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        cdb1[p] = gmc::splat2(0.f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cdw2[k][p] = gmc::splat2(0.f);
+    }
     uint4 pt[NT];
 #pragma unroll
-    for (int k = 0; k < ACC; ++k) acc[k] = gmc::f4_zero();
+    for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
@@ -737,10 +793,16 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
     // W == 8: a thread's rows' neighbour ids live in registers for the whole graph (both gathers):
     // no table in LDS, no table commit and one barrier less per graph
     uint4 idr[kRegIds ? ACC : 1];
+    // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
+    // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
     auto load_ids = [&](int r0, int n) {
+        const unsigned pad = (unsigned)n * 0x10001u;
 #pragma unroll
-        for (int k = 0; k < (kRegIds ? ACC : 1); ++k)
-            idr[k] = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(lrow + k * kRowsPerPass, n - 1)) * W);
+        for (int k = 0; k < (kRegIds ? ACC : 1); ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(l, n - 1)) * W);
+            idr[k] = l < n ? v : make_uint4(pad, pad, pad, pad);
+        }
     };
     auto commit_table = [&](int n) {  // (and the zero rows the padding entries point at)
         if constexpr (!kRegIds) {
@@ -770,41 +832,50 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
         STAMP(0);
         // (1) H -> Gs in place + column partials.  The row constants (GY2[r,:], dinv[r]) came with the
         // tile by DMA: an LDS read per row instead of a global-memory latency per row.  Pad columns
-        // need no masks: their W2 rows are 0 here and the H slab holds exact zeros there.
+        // need no masks: their W2 rows are 0 here and the H slab holds exact zeros there.  Rows past n
+        // work on the zero row n (h = 0 -> Gs = 0, partials += 0): no exec masks either.
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
             const float d = rck.w;
             dv[k] = d;
-            if (l < n) {  // in place: rows past n must not touch row n-1 again
-                const float gd[3] = {rck.x * d, rck.y * d, rck.z * d};
-                float4 *cell = reinterpret_cast<float4 *>(bufA) + l * Q + q;
-                const float4 h = *cell;
-                const float hv[4] = {h.x, h.y, h.z, h.w};
-                float gs[4];
+            if (ABL(7)) continue;
+            float4 *cell = reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q;
+            const float4 h = *cell;
+            const gmc::v2f g0 = gmc::splat2(rck.x * d), g1 = gmc::splat2(rck.y * d), g2 = gmc::splat2(rck.z * d);
+            const gmc::v2f hp[2] = {{h.x, h.y}, {h.z, h.w}};
+            gmc::v2f gs[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float ghd = gd[0] * w2[j][0] + gd[1] * w2[j][1] + gd[2] * w2[j][2];
-                    const float gpre = hv[j] > 0.f ? ghd : 0.f;  // relu' o dinv o (GY2 W2^T)
-                    gs[j] = gpre * d;
-                    colp[4 * j + 0] = fmaf(hv[j], gd[0], colp[4 * j + 0]);  // dW2 = (H o dinv)^T GY2
-                    colp[4 * j + 1] = fmaf(hv[j], gd[1], colp[4 * j + 1]);
-                    colp[4 * j + 2] = fmaf(hv[j], gd[2], colp[4 * j + 2]);
-                    colp[4 * j + 3] += gpre;                                // db1
-                }
-                *cell = make_float4(gs[0], gs[1], gs[2], gs[3]);
+            for (int p = 0; p < 2; ++p) {
+                gmc::v2f ghd = g0 * w2p[p][0];
+                ghd = gmc::pk_fma(g1, w2p[p][1], ghd);
+                ghd = gmc::pk_fma(g2, w2p[p][2], ghd);
+                const gmc::v2f gpre = {hp[p].x > 0.f ? ghd.x : 0.f, hp[p].y > 0.f ? ghd.y : 0.f};  // relu' o dinv o (GY2 W2^T)
+                gs[p] = gpre * gmc::splat2(d);
+                if (ABL(3)) continue;
+                cdw2[0][p] = gmc::pk_fma(hp[p], g0, cdw2[0][p]);  // dW2 = (H o dinv)^T GY2
+                cdw2[1][p] = gmc::pk_fma(hp[p], g1, cdw2[1][p]);
+                cdw2[2][p] = gmc::pk_fma(hp[p], g2, cdw2[2][p]);
+                cdb1[p] += gpre;                                  // db1
             }
+            *cell = make_float4(gs[0].x, gs[0].y, gs[1].x, gs[1].y);
+            // pin the partials here: their only user is the end of the graph loop, and left alone the
+            // optimiser sinks these FMAs past the gathers - keeping every row's h and g alive (600 B of
+            // scratch per lane)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                asm volatile("" : "+v"(cdw2[0][p]), "+v"(cdw2[1][p]), "+v"(cdw2[2][p]), "+v"(cdb1[p]));
         }
         STAMP(1);  // transform
-        __syncthreads();
+        loop_syncthreads();
         STAMP(2);  // barrier A
         // (2) U tile = dinv o (A @ Gs); rows past n redo row n-1 (same value to the same address)
         if constexpr (kRegIds) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = min(lrow + k * kRowsPerPass, n - 1);
-                float4 u = gather_ids8<FS, false>(bufA, idr[k], nullptr, q);
+                const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
+                float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false>(bufA, idr[k], nullptr, q);
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
@@ -820,29 +891,33 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
             }
         }
         STAMP(3);  // gather 1
-        __syncthreads();
+        loop_syncthreads();
         STAMP(4);  // barrier B
         // (3) next graph's H tile streams into bufA while (4) gathers from bufB
-        if (g + 1 < g1) fetch(r0n, nn);
+        if (g + 1 < g1 && !ABL(1)) fetch(r0n, nn);
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
         if constexpr (kRegIds) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n) gmc::f4_add(acc[k], gather_ids8<FS, HAS_VAL>(bufB, idr[k], HAS_VAL ? wbase + (long)l * W : nullptr, q));
+                const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
+                if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true>(bufB, idr[k], wbase + (long)l * W, q));
+                else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS>(bufB, idr[k], q);
+                // the sum is needed HERE (its only user is the store after the graph loop: left alone the
+                // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
+                asm volatile("" : "+v"(acc[k]));
             }
         } else {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = lrow + k * kRowsPerPass;
-                if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+                if (l < n) acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
             }
         }
         STAMP(6);  // gather 2
         dma_wait();
         STAMP(7);  // DMA wait
-        __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
+        loop_syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
         STAMP(8);  // barrier C
         if (g + 1 < g1) {
             // next graph's ids: requested now, first needed after the transform and barrier A
@@ -859,10 +934,17 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = acc[k];
+            if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = gmc::v4f_f4(acc[k]);
         }
     }
     // column partials: fold the lanes sharing q inside each wave, then the 16 waves (fixed order)
+    float colp[16];  // [j][0..2] dW2, [j][3] db1 for my 4 columns j
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { colp[4 * (2 * p) + k] = cdw2[k][p].x; colp[4 * (2 * p + 1) + k] = cdw2[k][p].y; }
+        colp[4 * (2 * p) + 3] = cdb1[p].x; colp[4 * (2 * p + 1) + 3] = cdb1[p].y;
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
 #pragma unroll
@@ -890,7 +972,8 @@ __global__ __launch_bounds__(kThreads) void bwd1_lds_kernel(Bwd1Args a) {
 // two tile buffers + table fit the CU's 160 KiB of LDS; 0 = does not fit (row kernels).
 int pick_fs(int n_max, int W) {
     if (n_max >= 65535 || (W != 8 && W != 16)) return 0;
-    for (int fs = 64; fs >= 16; fs >>= 1)
+    static const int cap = getenv("GMC_LDS_MAX_FS") ? atoi(getenv("GMC_LDS_MAX_FS")) : 64;  // tuning runs only
+    for (int fs = cap >= 16 ? cap : 64; fs >= 16; fs >>= 1)
         if (lds_bytes(n_max, W, fs) <= 160 * 1024) return fs;
     return 0;
 }
