@@ -28,10 +28,13 @@ def assign_partitions(node_probs: np.ndarray) -> List[int]:
     """One sample of the post-processing (host form, TestingNeuralNetwork.py:18-46)."""
     out = [0, 1, 2]
     for probs in node_probs[3:]:
-        r = np.random.rand()
-        running = 0
+        r = float(np.random.rand())
+        running = 0.0
         for i, p in enumerate(probs):
-            running += p
+            # double running sum, double compare: what `cumulative_prob = 0; += np.float32` does under
+            # the reference's pinned NumPy 1.x (envList.txt:105) - and what decode.hip does; written with
+            # Python floats so that the installed NumPy's promotion rules do not matter
+            running += float(p)
             if r < running:
                 out.append(i)
                 break

@@ -319,7 +319,13 @@ class FusedTrainer:
         self.local_shard = local_shard
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
+        if self.world > 1 and hasattr(self.eng, "sync_replicas"):
+            self.eng.sync_replicas(0)   # one model: rank 0's parameters / moments on every replica
         self._plan_key = None
+        self._ws: Optional[torch.Tensor] = None   # scratch of this trainer's steps (captured graphs point into it)
+        self._graph_key = None
+        self._dp_graph = None       # (per-step forward/backward hipGraphs, Adam hipGraph) of a data-parallel rank
+        self._dp_graph_key = None
         self.allow_graph = True     # set False to force eager launches (per-kernel probing)
         self._graph = None          # hipGraph of one whole epoch (single GPU)
         self._graph_steps = 0
@@ -330,10 +336,12 @@ class FusedTrainer:
         self._out = None
 
     def prepare(self, dataset: Dict) -> None:
-        key = (id(dataset), len(dataset), self.graphs_per_step, self.world)
+        items = list(dataset.values())
+        # (handles and adjacency tensors by identity + in-place version: a dataset edited in place is re-planned)
+        key = (id(dataset), self.graphs_per_step, self.world,
+               tuple((id(it[0]), id(it[1]), getattr(it[1], "_version", 0)) for it in items))
         if key == self._plan_key:
             return
-        items = list(dataset.values())
         gps, dev = self.graphs_per_step, self.eng.device
         self._batches = []
         stride = gps if self.local_shard else gps * self.world
@@ -355,8 +363,25 @@ class FusedTrainer:
                            if dev.type == "cuda" else None)
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
+        # private scratch, sized for the largest step: the engine's own scratch is re-allocated whenever a
+        # later call (evaluate_model on a bigger batch, another trainer) needs more, which would leave a
+        # captured hipGraph replaying into freed memory
+        if hasattr(self.eng, "workspace_bytes") and self._batches:
+            need = max((self.eng.workspace_bytes(b, True) for b in self._batches if b.B), default=0)
+            if need and (self._ws is None or self._ws.numel() < need):
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         self._plan_key = key
         self._graph = None
+        self._dp_graph = None
+
+    def _hyper(self):
+        """(lr, betas, eps) of the step: the optimizer's first param group, as ``optimizer.step()`` would use
+        (TrainingNeural.py:337,386); the config's learning rate when the optimizer carries none."""
+        groups = getattr(self.optimizer, "param_groups", None)
+        if groups:
+            g = groups[0]
+            return float(g.get("lr", self.config.learning_rate)), tuple(g.get("betas", (0.9, 0.999))), float(g.get("eps", 1e-8))
+        return float(self.config.learning_rate), (0.9, 0.999), 1e-8
 
     def epoch(self, dataset: Dict) -> float:
         """One pass over the dataset; returns the cumulative loss (one host sync)."""
@@ -372,13 +397,30 @@ class FusedTrainer:
             # in the slot after the gradient (GMC_MODEL_GRAD_TAIL), the all-reduce makes it the batch's
             tail = eng.grad[eng.count:eng.count + 1]
             last = len(self._batches) - 1
+            lr, betas, eps = self._hyper()
+            graphs = self._dp_graphs() if self._use_dp_graph() else None
+            if graphs is not None:
+                eng.step_dev.fill_(eng.step_count)
             for i, batch in enumerate(self._batches):
-                eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+                if batch.B == 0:
+                    # this rank's shard of the step is empty (last group smaller than the world): it
+                    # contributes a zero gradient and a ZERO loss - the tail slot still holds the previous
+                    # step's all-reduced loss and would otherwise be added once more per empty rank
+                    eng.grad[:eng.count + 1].zero_()
+                elif graphs is not None:
+                    graphs[0][i].replay()              # forward + loss + backward + gradient fold of my shard
+                else:
+                    eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]),
+                                      **({"ws": self._ws} if self._ws is not None else {}))
                 if self.world > 1:
-                    eng.allreduce_grad()
+                    eng.allreduce_grad()               # ONE RCCL all-reduce of [gradient | loss] per step, eager
                     if i != last:                      # the last step's slot is read in place below
                         self._step_loss[i:i + 1].copy_(tail)
-                eng.adam_step(cfg.learning_rate)
+                if graphs is not None:
+                    graphs[1].replay()                 # Adam, step number read from / advanced in device memory
+                    eng.step_count += 1
+                else:
+                    eng.adam_step(lr, betas, eps)
         if self.world > 1:   # one host sync per epoch
             if not self._batches:
                 return 0.0
@@ -414,16 +456,59 @@ class FusedTrainer:
                 and hasattr(self.eng, "train_step")
                 and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
 
+    def _use_dp_graph(self) -> bool:
+        """Data-parallel ranks: the launches on either side of the (eager) all-reduce are replayed from
+        hipGraphs - one per step for forward/loss/backward, one for Adam."""
+        return (self.allow_graph and self.world > 1 and hasattr(self.eng, "adam_step_dev") and self._ws is not None
+                and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
+
+    def _dp_graphs(self):
+        eng, cfg = self.eng, self.config
+        hyper = self._hyper()
+        key = (hyper, float(cfg.C), self._ws.data_ptr())
+        if self._dp_graph is not None and self._dp_graph_key == key:
+            return self._dp_graph
+        lr, betas, eps = hyper
+        fb = []
+        for i, batch in enumerate(self._batches):
+            if batch.B == 0:
+                fb.append(None)
+                continue
+            out = (self._out[0], self._out[1], self._loss_slots[i])
+            eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws)     # eager once: warms the kernels
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws)
+            fb.append(g)
+        before, flat, m, v = eng.step_count, eng.flat.clone(), eng.m.clone(), eng.v.clone()
+        eng.step_dev.fill_(eng.step_count)
+        eng.adam_step_dev(lr, betas, eps)                              # eager once (state restored below)
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            eng.adam_step_dev(lr, betas, eps)
+        eng.flat.copy_(flat); eng.m.copy_(m); eng.v.copy_(v)
+        eng.step_count = before
+        eng.step_dev.fill_(before)
+        self._dp_graph, self._dp_graph_key = (fb, ga), key
+        return self._dp_graph
+
     def _enqueue_epoch(self, with_readback: bool = False) -> None:
         eng, cfg = self.eng, self.config
+        lr, betas, eps = self._hyper()
         for i, batch in enumerate(self._batches):
-            eng.train_step(batch, cfg.learning_rate, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]))
+            eng.train_step(batch, lr, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]), betas=betas, eps=eps,
+                           ws=self._ws)
         if with_readback and self._loss_host is not None:
             self._loss_host.copy_(self._loss_slots, non_blocking=True)
 
     def _replay_epoch(self) -> None:
         eng = self.eng
         eng.step_dev.fill_(eng.step_count)
+        # the captured launches carry lr / betas / eps / C and the scratch pointer as kernel arguments
+        key = (self._hyper(), float(self.config.C), self._ws.data_ptr() if self._ws is not None else 0)
+        if self._graph is not None and key != self._graph_key:
+            self._graph = None
+        self._graph_key = key
         if self._graph is None:
             self._enqueue_epoch()                 # eager epoch: sizes the workspace, warms the kernels
             graph = torch.cuda.CUDAGraph()
@@ -474,6 +559,12 @@ def train_single_epoch(dataset: Dict, net, optimizer, embed, config: TrainingCon
     return cumulative_loss
 
 
+def _rank0() -> bool:
+    """Data-parallel runs: every rank holds the same model, rank 0 alone prints and writes checkpoints
+    (N processes writing ./epoch_*.pth at once would race on the same files)."""
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def _checkpoint(net, optimizer, embed, epoch, loss_history, config) -> Dict:
     tr = getattr(net, "_fused_trainer", None)
     if tr is not None:
@@ -486,9 +577,10 @@ def train_model(dataset: Dict, config: TrainingConfig, dataset_files: Optional[L
                 graphs_per_step: Optional[int] = None) -> Tuple:
     """Main training function (TrainingNeural.py:392-484):
     returns ``(model, best_loss, final_epoch, embedding_weights, loss_history)``."""
-    print(f"Starting training with {config.number_epochs} epochs")
-    print(f"Model: {config.n_nodes} nodes, {config.number_classes} classes")
-    print(f"Device: {TORCH_DEVICE}")
+    say = print if _rank0() else (lambda *a, **k: None)
+    say(f"Starting training with {config.number_epochs} epochs")
+    say(f"Model: {config.n_nodes} nodes, {config.number_classes} classes")
+    say(f"Device: {TORCH_DEVICE}")
 
     net, embed, optimizer = setup_model_and_optimizer(config)
     best_loss, best_model_state = float('inf'), None
@@ -506,7 +598,7 @@ def train_model(dataset: Dict, config: TrainingConfig, dataset_files: Optional[L
         if epoch > 0 and stalled:
             patience_counter += 1
             if patience_counter >= config.patience:
-                print(f'Early stopping at epoch {epoch}')
+                say(f'Early stopping at epoch {epoch}')
                 break
         else:
             patience_counter = 0
@@ -517,21 +609,21 @@ def train_model(dataset: Dict, config: TrainingConfig, dataset_files: Optional[L
         prev_loss = cumulative_loss
 
         if epoch % config.save_frequency == 0:
-            print(f'Epoch: {epoch}, Cumulative Loss: {cumulative_loss:.6f}')
-            if config.save_directory:
+            say(f'Epoch: {epoch}, Cumulative Loss: {cumulative_loss:.6f}')
+            if config.save_directory and _rank0():
                 torch.save(_checkpoint(net, optimizer, embed, epoch, loss_history, config),
                            f'./epoch_{epoch}_loss_{cumulative_loss:.4f}_{config.save_directory}')
 
     if best_model_state is not None:
         net.load_state_dict(best_model_state)
 
-    print(f'Training completed in {time() - start_time:.2f} seconds')
-    print(f'Best loss: {best_loss:.6f}')
+    say(f'Training completed in {time() - start_time:.2f} seconds')
+    say(f'Best loss: {best_loss:.6f}')
 
-    if config.save_directory:
+    if config.save_directory and _rank0():
         final_filename = f'./final_{config.save_directory}'
         torch.save(_checkpoint(net, optimizer, embed, epoch, loss_history, config), final_filename)
-        print(f'Final model saved to {final_filename}')
+        say(f'Final model saved to {final_filename}')
 
     return net, best_loss, epoch, embed.weight, loss_history
 

@@ -1,0 +1,413 @@
+// Fused layer-1 backward of the GCN (autograd of TrainingNeural.py:80-83, run by loss.backward() :385)
+// for graphs that fit a CU's LDS.  Shared tile machinery: lds_tile.h.
+#include "lds_tile.h"
+
+namespace {
+
+// ---- fused layer-1 backward: hidden backward + aggregation + dW1 in one pass over H --------
+//
+// Workgroup = (column slice, chunk of graphs).  Per graph: the H tile arrives by LDS-DMA; every
+// thread turns its own elements into Gs = dinv^2 o relu'(H) o (GY2 @ W2^T) IN PLACE (and adds
+// their dW2 / db1 terms to register partials); gather #1 builds the U tile = dinv o (A @ Gs) in
+// the second LDS buffer; the next graph's H tile is then DMA'd into the first buffer while
+// gather #2 accumulates dW1 += A_val @ U in registers.  Gs and U never exist in HBM: the whole
+// backward of layer 1 (autograd of TrainingNeural.py:80-83, run by loss.backward() :385)
+// reads H once.  Outputs: dW1 partial [chunk][n_max][F] and column partials [chunk][F][4]
+// = (dW2[f,0..2], db1[f]), folded in chunk order by fold_chunks / colsum_reduce.
+struct Bwd1Args {
+    gmc_batch b;
+    const float *H;       // slab layout [slice][R][FS]
+    const float *GY2;     // [R][4] = (GY2[r,0..2], dinv[r])
+    const float *W2;      // [F][3]
+    float *dw1part;       // [chunks][n_max][F]
+    float *colpart;       // [chunks][F][4]
+    int F;
+    int slices;
+    int chunks;
+    int graphs_per_chunk;
+};
+
+// per-thread state shared by the two kernel flavours: my 4 columns as two pairs p = (f0+2p, f0+2p+1) -
+// W2 rows and the dW2 / db1 partials live on 2-vectors (v_pk_fma_f32): the transform is VALU work on
+// every element of H
+struct ColState {
+    gmc::v2f w2p[2][3];
+    gmc::v2f cdw2[3][2], cdb1[2];  // dW2[pair, k] and db1[pair] partials of my rows
+};
+
+__device__ __forceinline__ void col_state_init(ColState &c, const float *W2, int f0, bool col_on) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            c.w2p[p][k] = col_on ? (gmc::v2f){W2[(long)(f0 + 2 * p) * 3 + k], W2[(long)(f0 + 2 * p + 1) * 3 + k]}
+                                 : gmc::splat2(0.f);
+            c.cdw2[k][p] = gmc::splat2(0.f);
+        }
+        c.cdb1[p] = gmc::splat2(0.f);
+    }
+}
+
+// (1) of the graph loop for ONE of my rows: H -> Gs = dinv^2 o relu'(H) o (GY2 @ W2^T) in place + the
+// row's dW2 / db1 terms.  rck = (GY2[r,0..2], dinv[r]).  Pad columns need no masks (their W2 rows are 0
+// here and the H slab holds exact zeros there); rows past n work on the zero row (h = 0 -> Gs = 0,
+// partials += 0): no exec masks either.
+__device__ __forceinline__ void transform_row(ColState &c, float4 *cell, const float4 rck) {
+    const float d = rck.w;
+    const float4 h = *cell;
+    const gmc::v2f g0 = gmc::splat2(rck.x * d), g1 = gmc::splat2(rck.y * d), g2 = gmc::splat2(rck.z * d);
+    const gmc::v2f hp[2] = {{h.x, h.y}, {h.z, h.w}};
+    gmc::v2f gs[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        gmc::v2f ghd = g0 * c.w2p[p][0];
+        ghd = gmc::pk_fma(g1, c.w2p[p][1], ghd);
+        ghd = gmc::pk_fma(g2, c.w2p[p][2], ghd);
+        const gmc::v2f gpre = {hp[p].x > 0.f ? ghd.x : 0.f, hp[p].y > 0.f ? ghd.y : 0.f};  // relu' o dinv o (GY2 W2^T)
+        gs[p] = gpre * gmc::splat2(d);
+        if (ABL(3)) continue;
+        c.cdw2[0][p] = gmc::pk_fma(hp[p], g0, c.cdw2[0][p]);  // dW2 = (H o dinv)^T GY2
+        c.cdw2[1][p] = gmc::pk_fma(hp[p], g1, c.cdw2[1][p]);
+        c.cdw2[2][p] = gmc::pk_fma(hp[p], g2, c.cdw2[2][p]);
+        c.cdb1[p] += gpre;                                    // db1
+    }
+    *cell = make_float4(gs[0].x, gs[0].y, gs[1].x, gs[1].y);
+    // pin the partials here: their only user is the end of the graph loop, and left alone the optimiser
+    // sinks these FMAs past the gathers - keeping every row's h and g alive (600 B of scratch per lane)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        asm volatile("" : "+v"(c.cdw2[0][p]), "+v"(c.cdw2[1][p]), "+v"(c.cdw2[2][p]), "+v"(c.cdb1[p]));
+}
+
+// after the graph loop: fold the column partials over the lanes sharing q inside each wave, then over the
+// waves through `red` (fixed order), one [F][4] = (dW2[f,0..2], db1[f]) row set per chunk.  Callers
+// make sure no wave still reads the buffer `red` aliases.
+template <int Q>
+__device__ __forceinline__ void col_epilogue(const ColState &c, float *red, float *colpart, int chunk, int s, int FS, int F) {
+    float colp[16];  // [j][0..2] dW2, [j][3] db1 for my 4 columns j
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { colp[4 * (2 * p) + k] = c.cdw2[k][p].x; colp[4 * (2 * p + 1) + k] = c.cdw2[k][p].y; }
+        colp[4 * (2 * p) + 3] = c.cdb1[p].x; colp[4 * (2 * p + 1) + 3] = c.cdb1[p].y;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int o = 32; o >= Q; o >>= 1) colp[i] += __shfl_xor(colp[i], o, GMC_WAVE);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < Q) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[(wave * Q + lane) * 16 + i] = colp[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < Q * 4) {  // thread = (q, j): column f = s*FS + 4q + j
+        const int qq = threadIdx.x / 4, j = threadIdx.x % 4;
+        if (s * FS + 4 * qq < F) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int wv = 0; wv < kThreads / 64; ++wv)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) o[cc] += red[(wv * Q + qq) * 16 + 4 * j + cc];
+            reinterpret_cast<float4 *>(colpart)[(long)chunk * F + s * FS + 4 * qq + j] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// the graph's row constants (GY2[r,:], dinv[r]), 16 B per row, by LDS-DMA (lane i -> row i)
+__device__ __forceinline__ void dma_row_consts(const float *GY2, int r0, int n, float *gyl) {
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)gyl;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // recompute the per-thread address here: hoisted out of the graph loop it is spilled
+    for (int i0 = 0; i0 < n; i0 += kThreads) {
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (unsigned)(i0 + (tid & ~63))));
+        if (i0 + tid < n) glds16(GY2 + (long)(r0 + i0 + tid) * 4, dst);
+    }
+}
+
+// ---- 8-slot tables (degree <= 8: every reference configuration) -------------------------------------
+// A thread's rows' neighbour ids live in registers for the whole graph (both gathers): no table in LDS.
+// Two barriers per graph:
+//     transform(g) [own cells]  -> A ->  gather #1 (bufA -> bufB)  -> B ->  DMA(g+1) -> bufA || gather #2
+// (the 16-slot flavour below needs three: its table lives in the LDS the second constants buffer uses)
+// * a thread transforms exactly the cells its own DMA instructions fetched, so the H tile of graph g+1
+//   needs no rendezvous between "landed" (the issuing wave's vmcnt) and the transform;
+// * the row constants are double-buffered (the second buffer is the LDS the 16-slot flavour keeps its
+//   table in) and fetched a graph ahead, between A and B, so barrier B publishes them;
+//   (Tried and dropped, measured same-box: pulling the H tile of graph g+2 into L2 with 4-byte LDS-DMA
+//   touches while the tile of g+1 streams in, so that the DMA runs at L2 latency - the kernel got 11 %
+//   SLOWER; the tile DMA's only shadow stays gather #2.)
+template <int FS, int ACC, bool HAS_VAL>
+__global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int W = 8;
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+    int chunk, s;
+    tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    float *bufA = lds, *bufB = lds + TF;
+    float *gy0 = lds + 2 * TF + (size_t)a.b.n_max * W / 2;   // the constants region ...
+    float *gy1 = lds + 2 * TF;                                // ... and the (unused) table region: 16 B per row each
+    float *red = bufB;  // cross-wave fold area, used after the graph loop
+    const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+    const int f0 = s * FS + 4 * q;
+    const bool col_on = f0 < a.F;
+    const float *Hs = a.H + (long)s * a.b.R * FS;  // my slice's slab
+    ColState cs;
+    col_state_init(cs, a.W2, f0, col_on);
+    gmc::v4f acc[ACC];
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
+
+    const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
+    if (g0 >= g1) return;
+
+    uint4 idr[ACC];
+    // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
+    // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
+    auto load_ids = [&](int r0, int n) {
+        const unsigned pad = (unsigned)n * 0x10001u;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            const uint4 v = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(l, n - 1)) * W);
+            idr[k] = l < n ? v : make_uint4(pad, pad, pad, pad);
+        }
+    };
+    auto zero_pads = [&](float *buf, int n) {  // the zero rows n..n+3 the padding entries point at
+        if (threadIdx.x < kPadRows * FS) buf[n * FS + threadIdx.x] = 0.f;
+    };
+    auto fetch_tile = [&](int r0, int n) {  // H tile of the graph at rows [r0, r0+n) -> bufA
+        dma_tile<FS, ACC>(Hs + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+    };
+
+    // graph offsets are scalar loads: each is requested one graph ahead of its first use
+    int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
+    int nn = g0 + 1 < g1 ? a.b.goff[g0 + 2] - (r0 + n) : 0;   // size of graph g+1 (0: none)
+    dma_row_consts(a.GY2, r0, n, gy0);
+    fetch_tile(r0, n);
+    load_ids(r0, n);
+    zero_pads(bufA, n);
+    dma_wait();
+    __syncthreads();
+    STAMP_DECL;
+    for (int g = g0; g < g1; ++g) {
+        const int cur = (g - g0) & 1;
+        const float *gyl = cur ? gy1 : gy0;
+        const int r0n = r0 + n;                                              // == goff[g + 1]
+        const int n2 = g + 2 < g1 ? a.b.goff[g + 3] - (r0n + nn) : 0;        // size of graph g+2 (0: none)
+        float dv[ACC];
+        STAMP(0);
+        // (1) my own cells of the H tile (landed: waited for below / in the prologue) -> Gs
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
+            dv[k] = rck.w;
+            if (ABL(7)) continue;
+            transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck);
+        }
+        // row constants of graph g+1 into the other buffer: published by barrier B
+        if (nn > 0 && !ABL(1)) dma_row_consts(a.GY2, r0n, nn, cur ? gy0 : gy1);
+        STAMP(1);  // transform
+        loop_barrier();
+        STAMP(2);  // barrier A: every Gs cell is written; every wave is done with gather #2 of graph g-1
+        // (2) U tile = dinv o (A @ Gs)
+        zero_pads(bufB, n);
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
+            float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false>(bufA, idr[k], nullptr, q);
+            u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
+            reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+        }
+        STAMP(3);  // gather 1
+        dma_wait();   // my share of graph g+1's row constants
+        loop_barrier();
+        STAMP(4);  // barrier B: U tile complete, bufA free, next row constants visible
+        // (3) next graph's H tile streams into bufA while (4) gathers from bufB
+        if (nn > 0 && !ABL(1)) {
+            fetch_tile(r0n, nn);
+            zero_pads(bufA, nn);
+        }
+        STAMP(5);  // fetch issue
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
+            if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true>(bufB, idr[k], wbase + (long)l * W, q));
+            else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS>(bufB, idr[k], q);
+            // the sum is needed HERE (its only user is the store after the graph loop: left alone the
+            // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
+            asm volatile("" : "+v"(acc[k]));
+        }
+        STAMP(6);  // gather 2
+        dma_wait();   // my cells of graph g+1's tile have landed
+        STAMP(7);  // DMA wait
+        if (nn > 0) load_ids(r0n, nn);   // first needed after the transform and barrier A
+        STAMP(9);
+        r0 = r0n; n = nn; nn = n2;
+    }
+    STAMP_FLUSH;
+    if (col_on) {
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = gmc::v4f_f4(acc[k]);
+        }
+    }
+    __syncthreads();  // gather #2 of the last graph is done everywhere: bufB becomes the fold area
+    col_epilogue<Q>(cs, red, a.colpart, chunk, s, FS, a.F);
+}
+
+// ---- 16-slot tables (degree 9..16): neighbour table in LDS, three barriers per graph ----------------
+template <int FS, int W, int ACC, bool HAS_VAL>
+__global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;
+    int chunk, s;
+    tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    float *bufA = lds, *bufB = lds + TF;
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
+    float *gyl = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [n][4] = (GY2[r,:], dinv[r]) of the graph
+    float *red = bufB;  // cross-wave fold area, used after the graph loop
+    const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+    const int f0 = s * FS + 4 * q;
+    const bool col_on = f0 < a.F;
+    const long slab = (long)s * a.b.R * FS;
+    ColState cs;
+    col_state_init(cs, a.W2, f0, col_on);
+    gmc::v4f acc[ACC];
+    uint4 pt[NT];
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
+
+    const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
+    if (g0 >= g1) return;
+    auto fetch = [&](int r0, int n) {  // H tile -> bufA (DMA); neighbour table -> registers
+        dma_tile<FS, ACC>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+        dma_row_consts(a.GY2, r0, n, gyl);
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto commit_table = [&](int n) {  // (and the zero rows the padding entries point at)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+        }
+        if (threadIdx.x < kPadRows * FS) {
+            bufA[n * FS + threadIdx.x] = 0.f;
+            bufB[n * FS + threadIdx.x] = 0.f;
+        }
+    };
+    // graph offsets are scalar loads: each is requested one graph ahead of its first use
+    int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
+    fetch(r0, n);
+    commit_table(n);
+    dma_wait();
+    __syncthreads();
+    for (int g = g0; g < g1; ++g) {
+        const int r0n = r0 + n;                                        // == goff[g + 1]
+        const int nn = g + 1 < g1 ? a.b.goff[g + 2] - r0n : n;         // next graph's size (used after gather 1)
+        float dv[ACC];
+        // (1) H -> Gs in place + column partials (row constants from LDS: they came with the tile)
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
+            dv[k] = rck.w;
+            transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck);
+        }
+        __syncthreads();
+        // (2) U tile = dinv o (A @ Gs)
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n) {
+                float4 u = gather_row<FS, W, false>(bufA, nb, nullptr, l, q);
+                u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
+                reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+            }
+        }
+        __syncthreads();
+        // (3) next graph's H tile streams into bufA while (4) gathers from bufB
+        if (g + 1 < g1) fetch(r0n, nn);
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < n) {
+                acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+                asm volatile("" : "+v"(acc[k]));
+            }
+        }
+        dma_wait();
+        __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
+        if (g + 1 < g1) commit_table(nn);
+        __syncthreads();
+        r0 = r0n; n = nn;
+    }
+    if (col_on) {
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRowsPerPass;
+            if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = gmc::v4f_f4(acc[k]);
+        }
+    }
+    col_epilogue<Q>(cs, red, a.colpart, chunk, s, FS, a.F);
+}
+
+template <int FS, int W>
+int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
+    constexpr int rows_per_pass = kThreads / (FS / 4);
+    const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
+    const int grid = a.slices * a.chunks;
+    const bool hv = a.b.ell_vals != nullptr;
+    if constexpr (W == 8) {
+        if (acc <= 4) return hv ? launch(bwd1_reg_kernel<FS, 4, true>, grid, lds, st, a)
+                                : launch(bwd1_reg_kernel<FS, 4, false>, grid, lds, st, a);
+        if (acc <= 8) return hv ? launch(bwd1_reg_kernel<FS, 8, true>, grid, lds, st, a)
+                                : launch(bwd1_reg_kernel<FS, 8, false>, grid, lds, st, a);
+    } else {
+        if (acc <= 4) return hv ? launch(bwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
+                                : launch(bwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
+        if (acc <= 8) return hv ? launch(bwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
+                                : launch(bwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    }
+    return GMC_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// fused layer-1 backward over the slab-layout H: dW1 partials [chunks][n_max][F] and column
+// partials [chunks][F][4] (dW2, db1)
+int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, const float *W2,
+                        float *dw1part, float *colpart, int F, int chunks, int graphs_per_chunk,
+                        hipStream_t st) {
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    GmcProbeScope probe(GMC_K_BWD1_FUSED, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_bwd1<64, 8>(a, lds, st);
+            case 32: return launch_bwd1<32, 8>(a, lds, st);
+            default: return launch_bwd1<16, 8>(a, lds, st);
+        }
+    }
+    switch (fs) {
+        case 64: return launch_bwd1<64, 16>(a, lds, st);
+        case 32: return launch_bwd1<32, 16>(a, lds, st);
+        default: return launch_bwd1<16, 16>(a, lds, st);
+    }
+}

@@ -2,9 +2,16 @@
 //
 // Replaces python/Testing/TestingNeuralNetwork.py:18-98 (the direct caller of the hot path in
 // BASELINE configs[4], 99.7 % of the reference's inference wall time):
-//   assign_partitions            :18-46  per non-terminal node one uniform draw, running
-//                                        float32 sum of the row compared in double, last class
-//                                        as fallback; nodes 0,1,2 fixed to 0,1,2
+//   assign_partitions            :18-46  per non-terminal node one uniform draw compared with the
+//                                        running sum of the row, last class as fallback; nodes 0,1,2
+//                                        fixed to 0,1,2.  Arithmetic of the reference's PINNED
+//                                        environment (envList.txt:105, NumPy 1.x): `cumulative_prob = 0`
+//                                        `+= np.float32` promotes to float64, so the running sum of the
+//                                        float32 probabilities is taken in DOUBLE and compared in double
+//                                        with the (double) draw.  (Under NumPy >= 2 the same source keeps
+//                                        the sum in float32 and compares in float32; the two differ only
+//                                        for a draw within ~6e-8 of a boundary - tests/test_gpu_parity.py
+//                                        has the directed cases.)
 //   calculate_cut_value          :48-64  sum of weights of edges whose endpoints differ
 //   post_processing_optimization :66-98  `iterations` samples, keep the strictly best (first wins)
 // The uniforms are generated on the HOST with numpy's global RNG in the reference's draw order
@@ -37,9 +44,8 @@ __global__ __launch_bounds__(256) void decode_sample_kernel(DecodeArgs a) {
         if (l >= 3) {
             const float *p = a.P + (long)(r0 + l) * 3;
             const double r = u[l - 3];
-            const float c0 = p[0], c1 = c0 + p[1], c2 = c1 + p[2];  // running float32 sum
-            c = r < (double)c0 ? 0 : (r < (double)c1 ? 1 : 2);      // r >= c2: fallback = last class
-            (void)c2;
+            const double c0 = (double)p[0], c1 = c0 + (double)p[1];   // running sum in double (NumPy 1.x)
+            c = r < c0 ? 0 : (r < c1 ? 1 : 2);                        // class 2: r < c2, or the fallback
         }
         sa[l] = (unsigned char)c;
         a.assign_all[(long)it * a.b.R + r0 + l] = (signed char)c;

@@ -1,0 +1,255 @@
+// Fused layer-1 forward of the GCN (TrainingNeural.py:80-83) for graphs that fit a CU's LDS.
+// Shared tile machinery: lds_tile.h.
+#include "lds_tile.h"
+
+#ifdef GMC_STAMP
+__device__ unsigned long long g_stamps[4096 * 16];
+extern "C" int gmc_debug_read_stamps(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
+namespace {
+
+// ---- fused layer-1 forward: W1 row gather + aggregation (+ fused H@W2) in one kernel ---------
+//
+// Workgroup = (graph, slice group).  Per slice: the W1 slice (rows 0..n-1 of the shared
+// [N,F] table, L2-resident) arrives in buffer A by LDS-DMA; gather #1 builds the T0 tile =
+// dinv o (A_val @ W1[:n]) in buffer B (the X@W1 of TrainingNeural.py:80 with X = padded
+// adjacency, :373); the next slice's W1 tile is then DMA'd into A while gather #2 produces
+// H = relu(dinv o (A @ T0) + b1) (:80-81) from B, with the layer-2 feature transform
+// (H o dinv) @ W2 (:83) accumulated in registers.  T0 never exists in HBM: the forward of layer 1
+// writes H once and reads only W1 (from L2) and the neighbour table.
+template <int FS, int W, int ACC, bool HAS_VAL>
+__global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
+    STAMP_DECL;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int Q = FS / 4;
+    constexpr int kRowsPerPass = kThreads / Q;
+    constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;  // table uint4 per thread
+    // Persistent workgroup: items (graph, slice group) are numbered graph-major and every workgroup
+    // owns a contiguous range of them (one workgroup per CU when the batch is large), so it walks
+    // through consecutive slices of one graph, then of the next.  The graph's table / scales are set up
+    // once per graph instead of once per item and the tile pipeline does not drain between the groups
+    // of a graph; what a group leaves behind is only its Zpart partial (same values as one
+    // workgroup per item: a graph's result does not depend on the batch it is part of).
+    const int total = a.b.B * a.groups;
+    const int it0 = (int)blockIdx.x * a.items_per_wg, it1 = min(total, it0 + a.items_per_wg);
+    if (it0 >= it1) return;
+    const int per = (a.slices + a.groups - 1) / a.groups;
+
+    const int TF = (int)tile_floats(a.b.n_max, FS);
+    float *bufA = lds, *bufB = lds + TF;
+    unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
+    // column constants of every slice, once per workgroup: [slices * FS] x (W2[c,0..2], b1[c])
+    float4 *cst = reinterpret_cast<float4 *>(nb + (size_t)a.b.n_max * W);
+    const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+
+    {   // (slices * FS <= 1024 = kThreads: one column per thread; pad columns hold zeros)
+        const int cc = threadIdx.x;
+        const bool c_on = cc < a.slices * FS;
+        float4 c = gmc::f4_zero();
+        if (c_on && cc < a.F) {
+            if (a.W2) { c.x = a.W2[(long)cc * 3]; c.y = a.W2[(long)cc * 3 + 1]; c.z = a.W2[(long)cc * 3 + 2]; }
+            if (a.bias) c.w = a.bias[cc];
+        }
+        if (c_on) cst[cc] = c;
+    }
+
+    for (int it = it0; it < it1;) {
+        const int g = it / a.groups;
+        const int it_end = min(it1, (g + 1) * a.groups);           // my items of graph g
+        const int s_lo = (it - g * a.groups) * per, s_hi = min(a.slices, (it_end - g * a.groups) * per);
+        const int r0 = a.b.goff[g];
+        const int n = a.b.goff[g + 1] - r0;
+        const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+        // W1 tile of slice s, row-major [N][ldx].  Pad columns (>= F, last slice only) load the last
+        // valid column group again: finite values, so that the masked scale below makes exact zeros
+        auto dma = [&](int s) {
+            dma_tile<FS, ACC>(a.X + min(s * FS + 4 * q, a.F - 4), a.x_rs, n, true, lrow, bufA);
+        };
+        if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
+        // graph prologue: every global read is issued before the first use (one memory latency)
+        dma(s_lo);
+        float sc[ACC];
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) sc[k] = a.scale[r0 + min(lrow + k * kRowsPerPass, n - 1)];
+        uint4 pt[NT];
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int i = threadIdx.x + k * kThreads;
+                if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+            }
+        }
+        if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
+            bufA[(long)n * FS + threadIdx.x] = 0.f;
+            bufB[(long)n * FS + threadIdx.x] = 0.f;
+        }
+        gmc::v2f z01[ACC];  // (Z[r,0], Z[r,1]) partial of my 4 columns, per row
+        float z2[ACC];      //  Z[r,2]
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) { z01[k] = gmc::splat2(0.f); z2[k] = 0.f; }
+        // a slice group's Zpart partial.  Called one gather later than the group ends (after the next
+        // slice's barrier 2): by then the group's H stores have long retired, so whatever vector-memory
+        // wait the compiler attaches to this rarely-run block (spill reloads) costs nothing
+        auto flush = [&](int grp) {
+            if (a.Zpart) {
+                float *zp = a.Zpart + ((long)grp * a.b.R + r0) * 3;
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    float z0 = z01[k].x, z1 = z01[k].y, zz = z2[k];
+#pragma unroll
+                    for (int o = Q / 2; o > 0; o >>= 1) {
+                        z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); zz += __shfl_xor(zz, o, GMC_WAVE);
+                    }
+                    int l = lrow + k * kRowsPerPass;
+                    asm volatile("" : "+v"(l));  // keeps the store addresses out of the slice loop's live set
+                    if (q == 0 && l < n) {
+                        zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = zz * sc[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) { z01[k] = gmc::splat2(0.f); z2[k] = 0.f; }
+        };
+        dma_wait();  // table / first tile
+        STAMP(11);  // prologue
+        for (int s = s_lo; s < s_hi; ++s) {
+            STAMP(0);  // loop overhead / previous tail
+            // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
+            if (s > s_lo && !ABL(1) && !ABL(2)) vm_wait<ACC>();
+            STAMP(1);  // DMA wait
+            loop_barrier();  // ... for every wave; readers of the previous T0 tile are done
+            STAMP(2);  // barrier 1
+            // gather #1: T0 tile
+            if constexpr (W == 8) {
+                uint4 ids = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const int l = lrow + k * kRowsPerPass;
+                    const uint4 cur = ids;
+                    if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                    // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
+                    const int lc = min(l, n - 1);
+                    float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
+                                      : gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                    t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                    reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const int l = lrow + k * kRowsPerPass;
+                    if (l < n) {
+                        float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                        t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
+                        reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+                    }
+                }
+            }
+            STAMP(3);  // gather 1
+            loop_barrier();
+            STAMP(4);  // barrier 2
+            if (s > s_lo && s % per == 0) flush(s / per - 1);  // the group that ended with slice s-1
+            if (s + 1 < s_hi && !ABL(1)) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+            STAMP(5);  // DMA issue
+            // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
+            // row n-1: same value to the same address) so that the vm_wait above counts exactly
+            // my 4 columns' constants (indexed by absolute column): W2 rows as (w0,w1) pairs + w2, bias pairs
+            const float4 c0 = cst[s * FS + 4 * q], c1 = cst[s * FS + 4 * q + 1], c2 = cst[s * FS + 4 * q + 2],
+                         c3 = cst[s * FS + 4 * q + 3];
+            const gmc::v2f w01[4] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}, {c3.x, c3.y}};
+            const float w2c[4] = {c0.z, c1.z, c2.z, c3.z};
+            const gmc::v2f blo = {c0.w, c1.w}, bhi = {c2.w, c3.w};
+            const bool col_pad = s * FS + 4 * q >= a.F;  // slab pad columns: stored as zeros
+            float *ydst = a.Y + (long)s * a.y_ss + 4 * q;
+            // pad columns: finite tile values (see dma) * scale 0 + bias 0 = exact zeros, no per-row select
+            float scm[ACC];
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
+            auto emit = [&](int k, const gmc::v4f acc) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                const gmc::v2f s2 = gmc::splat2(scm[k]);
+                const gmc::v2f ylo = gmc::pk_fma((gmc::v2f){acc.x, acc.y}, s2, blo);
+                const gmc::v2f yhi = gmc::pk_fma((gmc::v2f){acc.z, acc.w}, s2, bhi);
+                float4 y;
+                y.x = gmc::relu1(ylo.x); y.y = gmc::relu1(ylo.y); y.z = gmc::relu1(yhi.x); y.w = gmc::relu1(yhi.y);  // F.relu, :81
+                if (!ABL(2)) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+                if (ABL(3)) { z2[k] += y.x + y.y + y.z + y.w; return; }
+                // (H o dinv) @ W2 for my columns (:83; dinv applied at the flush): 4 packed + 4 scalar FMAs
+                z01[k] = gmc::pk_fma(gmc::splat2(y.x), w01[0], z01[k]); z2[k] = fmaf(y.x, w2c[0], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.y), w01[1], z01[k]); z2[k] = fmaf(y.y, w2c[1], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.z), w01[2], z01[k]); z2[k] = fmaf(y.z, w2c[2], z2[k]);
+                z01[k] = gmc::pk_fma(gmc::splat2(y.w), w01[3], z01[k]); z2[k] = fmaf(y.w, w2c[3], z2[k]);
+            };
+            uint4 ids2 = reinterpret_cast<const uint4 *>(nb)[min(lrow, n - 1)];
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                if constexpr (W == 8) {
+                    const uint4 cur = ids2;
+                    if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
+                    emit(k, ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS>(bufB, cur, q));
+                } else {
+                    emit(k, gmc::f4v(gather_row<FS, W, false>(bufB, nb, nullptr, l, q)));
+                }
+            }
+            STAMP(6);  // gather 2
+        }
+        flush((s_hi - 1) / per);  // last group of this graph segment
+        it = it_end;
+    }
+    STAMP(7);  // epilogue
+    STAMP_FLUSH;
+}
+
+template <int FS, int W>
+int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
+    constexpr int rows_per_pass = kThreads / (FS / 4);
+    const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
+    if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
+    if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    return GMC_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+// fused layer-1 forward: H (slab layout) = relu(dinv o (A @ (dinv o (A_val @ W1[:n]))) + b1) and
+// Zpart[group][r][:] = dinv[r] * (H[r, group's columns] @ W2[group's rows])
+int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, const float *W2, float *H,
+                        float *Zpart, int F, hipStream_t st) {
+    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    if (b->B == 0) return GMC_OK;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    const int slices = (F + fs - 1) / fs, groups = gmc_lds_groups(b, F);
+    // the column constants of every slice sit in LDS: 16 B per (padded) column
+    if ((size_t)slices * fs > (size_t)kThreads || (size_t)16 * slices * fs > lds_consts(b->n_max, fs)) return GMC_ERR_UNSUPPORTED;
+    // contiguous ranges of (graph, group) items, one persistent workgroup per CU when there are enough
+    const int total = b->B * groups, cus = device_cus();
+    const int ipw = (total + cus - 1) / cus, grid = (total + ipw - 1) / ipw;
+    TileArgs a{*b, W1, (long)F, (long)fs, 1, b->ell_vals != nullptr, b->dinv, b1, 1, H, (long)fs, (long)b->R * fs,
+               F, slices, groups, W2, Zpart, ipw};
+    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    GmcProbeScope probe(GMC_K_FWD1_FUSED, st);
+    if (b->ell_width == 8) {
+        switch (fs) {
+            case 64: return launch_fwd1<64, 8>(a, lds, grid, st);
+            case 32: return launch_fwd1<32, 8>(a, lds, grid, st);
+            default: return launch_fwd1<16, 8>(a, lds, grid, st);
+        }
+    }
+    switch (fs) {
+        case 64: return launch_fwd1<64, 16>(a, lds, grid, st);
+        case 32: return launch_fwd1<32, 16>(a, lds, grid, st);
+        default: return launch_fwd1<16, 16>(a, lds, grid, st);
+    }
+}

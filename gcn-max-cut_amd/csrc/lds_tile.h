@@ -1,0 +1,275 @@
+// Shared pieces of the LDS-tiled kernels (spmm_lds.hip, fwd1_lds.hip, bwd1_lds.hip): workgroup shape,
+// LDS budget, the LDS-DMA tile loader, the neighbour gathers and the launch helper.  Everything lives in an
+// anonymous namespace: each translation unit gets its own copy.
+#pragma once
+#include "gmc_common.h"
+#include <stdlib.h>
+
+
+// Diagnostic build only (-DGMC_STAMP, `make stamp`): wave 0 of every workgroup accumulates the
+// shader-clock cycles it spends in each phase of the fused kernels' tile loop into g_stamps
+// (never read by any kernel); gmc_debug_read_stamps copies them out.  The production library
+// contains none of this.
+#ifdef GMC_STAMP
+extern __device__ unsigned long long g_stamps[4096 * 16];  // defined in fwd1_lds.hip
+#define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {}
+#define STAMP(i)                                                     \
+    do {                                                             \
+        __builtin_amdgcn_sched_barrier(0);                           \
+        const unsigned long long st_now = __builtin_amdgcn_s_memtime(); \
+        st_acc[i] += st_now - st_last;                               \
+        st_last = st_now;                                            \
+        __builtin_amdgcn_sched_barrier(0);                           \
+    } while (0)
+#define STAMP_FLUSH                                                                    \
+    do {                                                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                     \
+            for (int i = 0; i < 12; ++i) g_stamps[blockIdx.x * 16 + i] = st_acc[i];    \
+    } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
+// Diagnostic builds only (`make variant NAME=ablN DEFS=-DGMC_ABLATE=N`, scratch/run_ablate.sh): remove
+// ONE component of the fused kernels' tile loop (results are then wrong by construction) to read off
+// what that component costs in place.  The production library compiles with GMC_ABLATE == 0.
+//   1 tile DMA after the first   2 global stores of the loop   3 fused W2 / column-partial math
+//   4 LDS reads of gather #2     5 LDS reads of gather #1      6 workgroup barriers of the loop
+//   7 bwd1: the H -> Gs transform
+#ifndef GMC_ABLATE
+#define GMC_ABLATE 0
+#endif
+#define ABL(n) (GMC_ABLATE == (n))
+
+namespace {
+
+// threads per workgroup of every kernel in this file; GMC_LDS_THREADS=512 builds the tuning variant
+// (two co-resident workgroups per CU when their LDS fits) - never the shipped library
+#ifndef GMC_LDS_THREADS
+#define GMC_LDS_THREADS 1024
+#endif
+constexpr int kThreads = GMC_LDS_THREADS;
+// 4 waves per SIMD either way (1 x 1024 or 2 x 512 threads per CU): 128 VGPRs per lane
+#define GMC_LDS_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+
+struct TileArgs {
+    gmc_batch b;
+    const float *X;     // source rows: batch rows (shared_src = 0) or one shared table (W1)
+    long x_rs, x_ss;    // element (row, col) of X lives at row*x_rs + (col/FS)*x_ss + col%FS:
+                        // row-major = (ld, FS); slab layout [slice][row][FS] = (FS, R*FS)
+    int shared_src;
+    int use_vals;
+    const float *scale;
+    const float *bias;
+    int relu;
+    float *Y;
+    long y_rs, y_ss;
+    int F;
+    int slices;          // ceil(F / FS)
+    int groups;          // slice groups per graph (workgroups per graph)
+    const float *W2;     // optional fused (Y o scale) @ W2
+    float *Zpart;        // [groups][R][3]
+    int items_per_wg;    // fwd1: (graph, group) items per persistent workgroup
+};
+
+// block -> (graph, group): all groups of a graph on one XCD (blocks are dealt round-robin
+// over the 8 XCDs), consecutive in that XCD's dispatch order.
+__device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
+    const int full = (B / 8) * 8 * S;
+    if (b < full) {
+        const int xcd = b & 7, j = b >> 3;
+        g = (j / S) * 8 + xcd;
+        s = j % S;
+    } else {
+        const int t = b - full;
+        const int rem = B - (B / 8) * 8;  // < 8 graphs left: interleave them
+        g = (B / 8) * 8 + t % rem;
+        s = t / rem;
+    }
+}
+
+
+// LDS: two tiles [(n_max + 4)][FS] floats (rows n..n+3 = zeros: the padding targets, one per
+// bank quarter, see ell_arrange.hip), then the neighbour table [n_max][W] of 16-bit ids.
+constexpr int kPadRows = 4;
+__host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + kPadRows) * FS; }
+constexpr int kMaxSlicesPerWg = 8;
+// third LDS region (after the two tiles and the table): the larger of
+//   - the column constants (bias, W2 rows): 16 B per column - every slice of up to 1024 columns for
+//     the persistent fused forward, kMaxSlicesPerWg slices for the SpMM (8 * FS * 16 B <= that);
+//   - the per-row constants (GY2[r,:], dinv[r]) of the graph in flight in bwd1: 16 B per row
+// (bwd1's cross-wave fold area of 256 * FS B re-uses a tile buffer after its graph loop).
+__host__ __device__ inline size_t lds_consts(int n_max, int FS) {
+    (void)FS;
+    const size_t cols = (size_t)16 * 1024, rows = (size_t)16 * (n_max + kPadRows);
+    return cols > rows ? cols : rows;
+}
+size_t lds_bytes(int n_max, int W, int FS) {
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + lds_consts(n_max, FS);
+}
+
+// Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
+// #(t + k*kThreads) of the tile = (row lrow + k*rows_per_pass, lane q) - exactly the (row, lane)
+// pairs it later produces.  No VGPRs are involved; a wave's 64 x 16 B land contiguously at a
+// wave-uniform LDS base, which is precisely the [row][FS] order of the tile.
+//
+// Issued through inline asm so hipcc does not see an LDS write: with the builtin it drains
+// vmcnt(0) before the next ds_read (it cannot prove the gather reads the OTHER buffer), which
+// serialises the DMA against the gather it is meant to overlap.  The price: completion is
+// ours to wait for - dma_wait() before the barrier that precedes the first read of the tile.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue
+// order): used to wait for a tile's DMA while the N stores issued after it stay in flight
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits
+// for every global store of the wave to be acknowledged - what the tile loops must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// the barriers inside the fused kernels' tile loops (removable in the GMC_ABLATE == 6 diagnostic build)
+__device__ __forceinline__ void loop_barrier() {
+    if (ABL(6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else lds_barrier();
+}
+__device__ __forceinline__ void loop_syncthreads() {
+    if (ABL(6)) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+
+template <int FS, int ACC>
+__device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
+    constexpr int kRowsPerPass = kThreads / (FS / 4);
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tile;
+    const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (threadIdx.x & ~63u)));
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) {
+        const int l = lrow + k * kRowsPerPass;
+        if (l < n && col_on) glds16(src_q + (long)l * rs, wave_dst + 16u * (unsigned)(k * kThreads));
+    }
+}
+
+
+// Read the eight tile rows named by eight packed u16 ids (lane's 16 B of each row).  The byte
+// address id * row_bytes + (tile + 16 q) is one v_mad_u32_u16 per row (op_sel picks the id's half
+// of the dword) instead of the unpack + shift-add pair the compiler emits: the gathers spend about
+// as many SIMD cycles on address arithmetic and adds as LDS cycles on the reads.
+__device__ __forceinline__ void read8(const float *tile, int q, unsigned row_bytes, const uint4 ids, float4 (&x)[8]) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    using lds_f4 = __attribute__((address_space(3))) const v4f;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
+    const unsigned pk[4] = {ids.x, ids.y, ids.z, ids.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned lo, hi;
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(lo) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+        asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+        const v4f a = *(lds_f4 *)(size_t)lo, b = *(lds_f4 *)(size_t)hi;
+        x[2 * j] = make_float4(a.x, a.y, a.z, a.w);
+        x[2 * j + 1] = make_float4(b.x, b.y, b.z, b.w);
+    }
+}
+
+// sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
+template <int FS, int W, bool HAS_VAL>
+__device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
+                                             int l, int q) {
+    float4 acc = gmc::f4_zero();
+#pragma unroll
+    for (int blk = 0; blk < W / 8; ++blk) {
+        const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
+        float4 x[8];
+        read8(tile, q, FS * 4, ids, x);
+        if (HAS_VAL) {  // weights come from HBM/L2: this (rare) variant waits on them per row
+            const float4 w0 = *reinterpret_cast<const float4 *>(wrow + blk * 8);
+            const float4 w1 = *reinterpret_cast<const float4 *>(wrow + blk * 8 + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+        } else if (blk == 0) {  // last read first: one wait per block (see gather_ids8)
+            acc = x[7];
+#pragma unroll
+            for (int u = 6; u >= 0; --u) gmc::f4_add(acc, x[u]);
+        } else {
+#pragma unroll
+            for (int u = 7; u >= 0; --u) gmc::f4_add(acc, x[u]);
+        }
+    }
+    return acc;
+}
+
+// gather_row with the row's ids already fetched (W == 8: one uint4).  Callers issue the id read of
+// their NEXT row before calling, so that it returns (LDS answers in order) under the same wait as
+// this row's eight reads and no row read ever sits behind an id read of its own.
+template <int FS, bool HAS_VAL>
+__device__ __forceinline__ float4 gather_ids8(const float *tile, const uint4 ids, const float *wrow, int q) {
+    float4 x[8];
+    read8(tile, q, FS * 4, ids, x);
+    float4 acc;
+    if (HAS_VAL) {
+        const float4 w0 = *reinterpret_cast<const float4 *>(wrow);
+        const float4 w1 = *reinterpret_cast<const float4 *>(wrow + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        acc = make_float4(w[0] * x[0].x, w[0] * x[0].y, w[0] * x[0].z, w[0] * x[0].w);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+    } else {
+        // Summed from the last read back: the first add then waits for all eight reads at once
+        // (LDS answers in order) and the row costs one s_waitcnt instead of eight.  These kernels
+        // are instruction-issue bound (rocprofv3: some instruction active 84 % of SIMD time), so
+        // every instruction saved per row counts.  Starts from x[7], not 0 + x[7]: the compiler
+        // may not drop an add of +0.0.
+        acc = x[7];
+#pragma unroll
+        for (int u = 6; u >= 0; --u) gmc::f4_add(acc, x[u]);
+    }
+    return acc;
+}
+
+// gather_ids8 for unit weights with the sum written on 2-vectors: 14 v_pk_add_f32 per row wherever it
+// is inlined (left to the SLP vectoriser, gather #2 of the fused forward came out as 28 v_add_f32).
+template <int FS>
+__device__ __forceinline__ gmc::v4f gather_ids8_pk(const float *tile, const uint4 ids, int q) {
+    float4 x[8];
+    read8(tile, q, FS * 4, ids, x);
+    gmc::v2f lo = {x[7].x, x[7].y}, hi = {x[7].z, x[7].w};  // from the last read back: one wait per row
+#pragma unroll
+    for (int u = 6; u >= 0; --u) {
+        lo += (gmc::v2f){x[u].x, x[u].y};
+        hi += (gmc::v2f){x[u].z, x[u].w};
+    }
+    return (gmc::v4f){lo.x, lo.y, hi.x, hi.y};
+}
+
+// Slice width for graphs of up to n_max nodes with W neighbour slots: the widest slice whose
+// two tile buffers + table fit the CU's 160 KiB of LDS; 0 = does not fit (row kernels).
+int pick_fs(int n_max, int W) {
+    if (n_max >= 65535 || (W != 8 && W != 16)) return 0;
+    static const int cap = getenv("GMC_LDS_MAX_FS") ? atoi(getenv("GMC_LDS_MAX_FS")) : 64;  // tuning runs only
+    for (int fs = cap >= 16 ? cap : 64; fs >= 16; fs >>= 1)
+        if (lds_bytes(n_max, W, fs) <= 160 * 1024) return fs;
+    return 0;
+}
+
+template <typename K, typename A>
+int launch(K k, int grid, size_t lds, hipStream_t st, const A &args) {
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, args);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}
+
+}  // namespace
+
+// host-side queries shared by the three translation units (defined in spmm_lds.hip)
+int gmc_lds_slice_width(const gmc_batch *b);
+bool gmc_lds_fits(const gmc_batch *b);
+int gmc_lds_slices(const gmc_batch *b, int F);
+int gmc_lds_groups(const gmc_batch *b, int F);
+int device_cus(bool allow_override = true);

@@ -108,19 +108,21 @@ class FusedEngine:
         hip.check(rc, "gmc_forward")
         return P, S, loss
 
-    def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None):
+    def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None, ws: Optional[torch.Tensor] = None):
         """forward + loss + backward for the batch's summed loss; gradient lands in
-        ``self.grad[:count]`` - TrainingNeural.py:373-385."""
+        ``self.grad[:count]`` - TrainingNeural.py:373-385.  ``ws``: caller-owned scratch (a trainer
+        whose launches are captured into a hipGraph must own it: the engine's own scratch moves
+        whenever a later call needs more)."""
         if out is None:
             P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
             S = torch.empty(batch.R, dtype=torch.int32, device=self.device)
             loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
         else:
             P, S, loss = out
-        if batch.B == 0:   # no graphs: zero gradient, nothing to launch
-            self.grad[:self.count].zero_()
+        if batch.B == 0:   # no graphs: zero gradient AND zero loss in the tail slot, nothing to launch
+            self.grad[:self.count + 1].zero_()
             return P, S, loss
-        ws, nbytes = self._workspace(batch, True)
+        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, True)
         rc = self.lib.gmc_train_fwd_bwd(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
                                         hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad),
                                         hip.stream())
@@ -128,11 +130,11 @@ class FusedEngine:
         return P, S, loss
 
     def train_step(self, batch: GraphBatch, lr: float, C_: float = 1.0, out=None, betas=(0.9, 0.999),
-                   eps: float = 1e-8):
+                   eps: float = 1e-8, ws: Optional[torch.Tensor] = None):
         """One whole optimizer step (forward, loss, backward, fused gradient fold + Adam) - the
         single-GPU form of the loop body of train_single_epoch (TrainingNeural.py:373-386).
         Replay-invariant: the step number is read from / advanced in device memory."""
-        ws, nbytes = self._workspace(batch, True)
+        ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, True)
         if out is None:
             P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
             S = torch.empty(batch.R, dtype=torch.int32, device=self.device)
@@ -175,6 +177,19 @@ class FusedEngine:
                                            hip.ptr(self.step_dev), hip.stream())
         hip.check(rc, "gmc_adam_devstep_f32")
         self.step_count += 1
+
+    def sync_replicas(self, src: int = 0) -> None:
+        """Data-parallel start-up: every rank takes rank ``src``'s parameters, Adam moments and step
+        count, so that replicas built from different RNG states apply the all-reduced gradient to the
+        SAME weights (the reference has one model; N replicas must be that one model)."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        for buf in (self.flat, self.m, self.v):
+            dist.broadcast(buf, src)
+        step = torch.tensor([self.step_count], dtype=torch.int64, device=self.device)
+        dist.broadcast(step, src)
+        self.step_count = int(step.item())
+        self.step_dev.fill_(self.step_count)
 
     def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""

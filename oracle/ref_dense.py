@@ -323,15 +323,39 @@ def cut_value(assign: Sequence[int], nx_graph) -> int:
 
 
 def sample_partition(probs: np.ndarray, rng_rand) -> List[int]:
-    """Testing/TestingNeuralNetwork.py:18-46: one uniform draw per non-terminal
-    node, running float32 sum of the row compared in double, last class as
-    fallback.  ``rng_rand`` is ``np.random.rand``-like."""
+    """Testing/TestingNeuralNetwork.py:18-46: one uniform draw per non-terminal node, compared with
+    the running sum of the row, last class as fallback.  ``rng_rand`` is ``np.random.rand``-like.
+
+    STATED SEMANTICS (they depend on the NumPy the reference runs under): the reference's pinned
+    environment is NumPy 1.x (envList.txt:105), where ``cumulative_prob = 0; cumulative_prob +=
+    np.float32`` promotes to float64 - the float32 probabilities are summed in DOUBLE and compared in
+    double with the draw.  That is what this function (and decode.hip) does, written with explicit
+    Python floats so that it does not depend on the NumPy installed here.  Under NumPy >= 2 (NEP 50)
+    the reference's source would keep a float32 sum and compare in float32; the two agree unless a
+    draw lies within ~6e-8 of a cumulative boundary (see :func:`sample_partition_numpy2`)."""
     out = [0, 1, 2]
     for row in probs[3:]:
-        r = rng_rand()
-        acc = 0
+        r = float(rng_rand())
+        acc = 0.0
         for i, pr in enumerate(row):
-            acc += pr
+            acc += float(pr)
+            if r < acc:
+                out.append(i)
+                break
+        else:
+            out.append(len(row) - 1)
+    return out
+
+
+def sample_partition_numpy2(probs: np.ndarray, rng_rand) -> List[int]:
+    """The same lines under NumPy >= 2 promotion (float32 running sum, draw rounded to float32 for the
+    comparison) - only used by tests to show where the two environments part."""
+    out = [0, 1, 2]
+    for row in probs[3:]:
+        r = np.float32(rng_rand())
+        acc = np.float32(0)
+        for i, pr in enumerate(row):
+            acc = np.float32(acc + np.float32(pr))
             if r < acc:
                 out.append(i)
                 break

@@ -1,7 +1,7 @@
 #!/bin/bash
-# usage: scratch/khist.sh <mangled-name-substring> : per-barrier-segment instruction histograms of a kernel in /tmp/spmm_lds.s
+# usage: scratch/khist.sh <mangled-name-substring> : per-barrier-segment instruction histograms of a kernel in ${ASM:-/tmp/spmm_lds.s}
 name=$1
-awk -v n="$name" '$0 ~ "^_ZN.*"n".*:" {on=1} on{print} on && /s_endpgm/{exit}' /tmp/spmm_lds.s > /tmp/k.s
+awk -v n="$name" '$0 ~ "^_ZN.*"n".*:" {on=1} on{print} on && /s_endpgm/{exit}' ${ASM:-/tmp/spmm_lds.s} > /tmp/k.s
 grep -n "s_barrier" /tmp/k.s | cut -d: -f1 | tr '\n' ' '; echo
 prev=1
 for b in $(grep -n "s_barrier" /tmp/k.s | cut -d: -f1) $(wc -l < /tmp/k.s); do

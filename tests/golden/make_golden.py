@@ -70,7 +70,12 @@ def main():
                       "post_iterations": 25, "post_assignment": [int(x) for x in best],
                       "post_cut": int(best_cut)})
     json.dump({"source": "python/Testing/TestingNeuralNetwork.py (reference, run here)",
-               "numpy": np.__version__, "cases": cases}, open(os.path.join(HERE, "decode.json"), "w"))
+               "numpy": np.__version__,
+               "note": "generated under NumPy >= 2 (NEP 50): assign_partitions keeps a float32 running sum and compares the "
+                       "draw in float32 there, while the reference's pinned NumPy 1.x (envList.txt:105) sums and compares "
+                       "in float64 - the semantics decode.hip and the oracle follow. The two differ only for a draw within "
+                       "~6e-8 of a cumulative boundary; no draw in these cases is that close (checked by the tests).",
+               "cases": cases}, open(os.path.join(HERE, "decode.json"), "w"))
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".json")])
 
 

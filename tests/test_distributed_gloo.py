@@ -61,12 +61,16 @@ class OracleEngine:
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
 
-    def adam_step(self, lr):
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8):
         self.step_count += 1
-        self.CO.adam(self.flat, self.grad[:self.count].numpy().copy(), self.m, self.v, lr, self.step_count)
+        self.CO.adam(self.flat, self.grad[:self.count].numpy().copy(), self.m, self.v, lr, self.step_count, betas[0], betas[1], eps)
+
+    def sync_replicas(self, src=0):   # the FusedEngine method of the same name, on numpy buffers
+        for buf in (self.flat, self.m, self.v):
+            dist.broadcast(torch.from_numpy(buf), src)
 
 
-def run_epochs(rank, world, port, graphs_per_step, queue):
+def run_epochs(rank, world, port, graphs_per_step, queue, n_graphs=6, seed_by_rank=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -76,10 +80,11 @@ def run_epochs(rank, world, port, graphs_per_step, queue):
     from tests import util
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        ds = util.product_dataset(SPECS)
+        ds = util.product_dataset(SPECS[:n_graphs])
     cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=HIDDEN)
     net, embed, opt = T.setup_model_and_optimizer(cfg)
-    params = {k: v.numpy() for k, v in R.init_params(1000, HIDDEN, 3, seed=4).items()}
+    # seed_by_rank: every rank starts from its OWN random model; the trainer must make them one (rank 0's)
+    params = {k: v.numpy() for k, v in R.init_params(1000, HIDDEN, 3, seed=4 + (rank if seed_by_rank else 0)).items()}
     eng = OracleEngine(params)
     tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=graphs_per_step, engine=eng)
     assert tr.world == world and tr.rank == rank
@@ -101,11 +106,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, graphs_per_step):
+def launch(world, graphs_per_step, n_graphs=6, seed_by_rank=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_epochs, args=(r, world, port, graphs_per_step, q)) for r in range(world)]
+    procs = [ctx.Process(target=run_epochs, args=(r, world, port, graphs_per_step, q, n_graphs, seed_by_rank)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -126,3 +131,28 @@ def test_two_ranks_reproduce_the_single_process_batched_step(built):
     assert np.abs(r0[3] - grad1).max() <= 1e-5 * max(1.0, np.abs(grad1).max())
     sure = np.abs(grad1) > 1e-4                 # Adam: +-lr steps where the gradient sign is decided
     assert np.abs(r0[2] - flat1)[sure].max() < 5e-5
+
+
+@pytest.mark.timeout(300)
+def test_uneven_last_group_leaves_a_rank_without_graphs(built):
+    """5 graphs, 2 ranks, 1 graph per rank per step: the last group holds one graph, so rank 1's shard of
+    that step is EMPTY.  It must contribute a zero gradient and a zero loss (its gradient buffer's tail
+    slot still holds the previous step's all-reduced loss) - the run equals the single-process run with
+    groups of 2, 2, 1 graphs."""
+    (_, loss1, flat1, grad1, sizes1), = launch(1, 2, n_graphs=5)
+    r0, r1 = launch(2, 1, n_graphs=5)
+    assert sizes1 == [2, 2, 1] and r0[4] == [1, 1, 1] and r1[4] == [1, 1, 0]
+    assert r0[1] == r1[1] == loss1              # cumulative loss per epoch: no step counted twice
+    assert np.array_equal(r0[2], r1[2])
+    sure = np.abs(grad1) > 1e-4
+    assert np.abs(r0[2] - flat1)[sure].max() < 5e-5
+
+
+@pytest.mark.timeout(300)
+def test_replicas_start_from_rank_zeros_model(built):
+    """Ranks that initialise their model from different RNG states must still train ONE model: the trainer
+    broadcasts rank 0's parameters / Adam state before the first step (there is no other broadcast)."""
+    (_, loss1, flat1, _g, _s), = launch(1, 6)                  # rank 0's seed, single process
+    r0, r1 = launch(2, 3, seed_by_rank=True)
+    assert np.array_equal(r0[2], r1[2])                        # bit-identical replicas
+    assert r0[1] == r1[1] == loss1

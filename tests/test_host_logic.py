@@ -184,3 +184,43 @@ def test_sharding_helpers(built):
         assert sum(parts, []) == list(range(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
     offs, total = flat_layout(1000, 500, 3)
     assert offs == [0, 500000, 500500, 502000, 502003] and total == 502003
+
+
+def test_bench_launcher_refuses_cleanly_without_gpus():
+    """`bench.py --gpus N` (N > 1) spawns its own ranks; with fewer visible devices than ranks it must say so
+    and exit non-zero BEFORE starting anything (here: no GPU at all)."""
+    import subprocess, sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the launcher would really launch")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "GCN_MAXCUT_BENCH_REHEARSE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 2 and "refusing to launch" in out.stderr and out.stdout.strip() == ""
+
+
+def test_sampler_semantics_are_numpy_version_independent(built, monkeypatch):
+    """assign_partitions (TestingNeuralNetwork.py:18-46): host form and oracle use the pinned NumPy 1.x
+    arithmetic (float64 running sum and compare) whatever NumPy is installed; on draws one ulp either side of
+    the boundaries that differs from the NumPy >= 2 reading (float32 sum, float32 compare)."""
+    from gcn_max_cut_amd.Testing import TestingNeuralNetwork as TN
+    rng = np.random.RandomState(1)
+    n = 44
+    probs, draws = np.empty((n, 3), np.float32), []
+    for l in range(n):
+        a, b = rng.uniform(0.05, 0.45, 2)
+        p0, p1 = np.float32(a), np.float32(b)
+        probs[l] = [p0, p1, np.float32(1.0) - p0 - p1]
+        if l >= 3:
+            c0, c1_64, c1_32 = float(p0), float(p0) + float(p1), float(np.float32(p0 + p1))
+            draws.append([np.nextafter(c0, 0.0), c0, np.nextafter(c1_64, 0.0), c1_64, 0.5 * (c1_64 + c1_32),
+                          np.nextafter(c0, 1.0)][(l - 3) % 6])
+    it = iter(draws)
+    monkeypatch.setattr(np.random, "rand", lambda: next(it))
+    host = TN.assign_partitions(probs)
+    it2, it3 = iter(draws), iter(draws)
+    ref = R.sample_partition(probs, lambda: next(it2))
+    np2 = R.sample_partition_numpy2(probs, lambda: next(it3))
+    assert host == ref and ref != np2
+    # kind 0 (draw just below the first boundary): double compare -> class 0; float32 compare -> not class 0
+    assert ref[3] == 0 and np2[3] != 0
