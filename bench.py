@@ -316,7 +316,8 @@ def main():
         if tag in kmean:
             dur = kmean[tag] * 1e-3
             rec = traffic_f.get(tag) if traffic_f.get("rows") == R_ and traffic_f.get("F") == F_ else None
-            fused[tag] = {"kernel": tag.replace("_fused", "_lds_kernel"), "bound": "hbm", "achieved": compulsory / dur / 1e9,
+            fused[tag] = {"kernel": {"fwd1_fused": "fwd1_lds_kernel", "bwd1_fused": "bwd1_reg_kernel"}[tag], "bound": "hbm",
+                          "achieved": compulsory / dur / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": compulsory / dur / 1e9 / HBM_PEAK_GBS,
                           "traffic": rec, "compulsory_bytes_per_launch": compulsory, "compulsory_bytes_are": what,
                           "mean_launch_us": dur * 1e6}

@@ -93,6 +93,7 @@ class _GCNForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, batch, *params):
         eng = net.engine()
+        ctx.dropout = eng.dropout_state()    # (p, seed) this forward runs with: the backward needs the same p
         ws = torch.empty(eng.workspace_bytes(batch, True), dtype=torch.uint8, device=eng.device)
         P, _, _ = eng.forward(batch, ws=ws)
         ctx.net, ctx.batch, ctx.ws = net, batch, ws
@@ -103,8 +104,13 @@ class _GCNForward(torch.autograd.Function):
     def backward(ctx, gp):
         (P,) = ctx.saved_tensors
         eng = ctx.net.engine()
-        g = eng.backward_from_gp(ctx.batch, P, gp.to(torch.float32), ws=ctx.ws)
-        return (None, None) + tuple(g[k].clone() for k in PARAM_ORDER)
+        now = eng.dropout_state()
+        eng.set_dropout(*ctx.dropout)
+        try:
+            g = eng.backward_from_gp(ctx.batch, P, gp.to(torch.float32), ws=ctx.ws)
+            return (None, None) + tuple(g[k].clone() for k in PARAM_ORDER)
+        finally:
+            eng.set_dropout(*now)
 
 
 class GCNSoftmax(nn.Module):
@@ -127,21 +133,26 @@ class GCNSoftmax(nn.Module):
         return self._engine
 
     def forward(self, g, inputs):
-        if self.training and self.dropout_frac > 0.0:
-            raise NotImplementedError("dropout > 0 is not implemented on the fused HIP path "
-                                      "(every reference configuration uses dropout=0.0)")
         eng = self.engine()
         try:
             batch = graph_batch_of(g, inputs, eng.device)
         except NotImplementedError:
             return self._forward_dense_features(g, inputs)
         params = [dict(self.named_parameters())[k] for k in PARAM_ORDER]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _GCNForward.apply(self, batch, *params)
-        P, _, _ = eng.forward(batch)
-        return P
+        # F.dropout(h, p=self.dropout_frac, training=self.training) (:82): a fresh mask per call in train mode;
+        # the engine's dropout is 0 outside of such a call (evaluate_model, decode, the trainer's own steps)
+        eng.set_dropout(self.dropout_frac if self.training else 0.0)
+        try:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return _GCNForward.apply(self, batch, *params)
+            P, _, _ = eng.forward(batch)
+            return P
+        finally:
+            eng.set_dropout(0.0)
 
     def _forward_dense_features(self, g, inputs):
+        if self.training and self.dropout_frac > 0.0:
+            raise NotImplementedError("dropout > 0 with features that are not the padded adjacency")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
                 "gradients are implemented for the reference's usage net(g, padded_adjacency) "
@@ -367,7 +378,12 @@ class FusedTrainer:
         # later call (evaluate_model on a bigger batch, another trainer) needs more, which would leave a
         # captured hipGraph replaying into freed memory
         if hasattr(self.eng, "workspace_bytes") and self._batches:
+            drop = float(getattr(self.net, "dropout_frac", 0.0) or 0.0)
+            if drop > 0.0:   # the dropout sequence needs a little more scratch: size for it
+                self.eng.set_dropout(drop, 0)
             need = max((self.eng.workspace_bytes(b, True) for b in self._batches if b.B), default=0)
+            if drop > 0.0:
+                self.eng.set_dropout(0.0)
             if need and (self._ws is None or self._ws.numel() < need):
                 self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
         self._plan_key = key
@@ -383,10 +399,34 @@ class FusedTrainer:
             return float(g.get("lr", self.config.learning_rate)), tuple(g.get("betas", (0.9, 0.999))), float(g.get("eps", 1e-8))
         return float(self.config.learning_rate), (0.9, 0.999), 1e-8
 
+    def _dropout(self) -> float:
+        """p of F.dropout for this epoch's steps (TrainingNeural.py:82): the model's, in train mode."""
+        return float(getattr(self.net, "dropout_frac", 0.0)) if getattr(self.net, "training", False) else 0.0
+
     def epoch(self, dataset: Dict) -> float:
         """One pass over the dataset; returns the cumulative loss (one host sync)."""
         self.prepare(dataset)
         eng, cfg = self.eng, self.config
+        drop = self._dropout()
+        if hasattr(eng, "set_dropout") and drop == 0.0:
+            eng.set_dropout(0.0)
+        if drop > 0.0:
+            # dropout: eager launches of the one-kernel-per-operation sequence, a fresh mask per step (the
+            # captured graphs would replay one mask; every reference configuration trains with p = 0)
+            lr, betas, eps = self._hyper()
+            tail = eng.grad[eng.count:eng.count + 1]
+            for i, batch in enumerate(self._batches):
+                eng.set_dropout(drop)
+                if batch.B == 0:
+                    eng.grad[:eng.count + 1].zero_()
+                else:
+                    eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]), ws=self._ws)
+                if self.world > 1:
+                    eng.allreduce_grad()
+                self._step_loss[i:i + 1].copy_(tail)
+                eng.adam_step(lr, betas, eps)
+            eng.set_dropout(0.0)
+            return float(self._step_loss.cpu().numpy().sum(dtype=np.float64))
         if self._use_graph():
             self._replay_epoch()
         elif self.world == 1 and hasattr(eng, "train_step"):

@@ -33,6 +33,9 @@ bool gmc_lds_fits(const gmc_batch *b);
 int gmc_lds_groups(const gmc_batch *b, int F);
 int gmc_spmm_lds_launch(const gmc_batch *, const float *, long, int, int, int, const float *, const float *, int,
                         float *, long, int, int, const float *, float *, int, hipStream_t);
+int gmc_dropout_launch(float *, long, int, int, long, float, unsigned long long, hipStream_t);
+int gmc_hw2_rows_launch(const float *, const float *, const float *, float *, long, int, int, long, hipStream_t);
+int gmc_scale_copy_launch(const float *, float *, int, float, hipStream_t);
 
 namespace {
 
@@ -47,8 +50,12 @@ struct Workspace {
     float *part;     // [tiles,F,4]
     float *db2part;  // [B,3]
     float *dw1part;  // [chunks,N,F]
+    float *W2s;      // [F,3] = W2 / (1-p), dropout only (last, so that forward-only carving shares the prefix)
     size_t bytes;
 };
+
+bool dropout_on(const gmc_model *m) { return m->dropout_p > 0.f; }
+unsigned long long dropout_seed(const gmc_model *m) { return ((unsigned long long)m->dropout_seed_hi << 32) | m->dropout_seed_lo; }
 
 // GMC_SPMM_ALGO=rows|lds forces one SpMM implementation (A/B runs recorded under profiles/);
 // default: LDS-staged tiles whenever the largest graph fits a CU's LDS.
@@ -82,7 +89,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     const size_t R = (size_t)b->R, F = (size_t)m->F;
     w.ld = (long)((F + 31) / 32 * 32);
     w.fs = use_lds(b) ? gmc_lds_slice_width(b) : 0;
-    w.zparts = w.fs ? gmc_lds_groups(b, m->F) : 1;
+    w.zparts = (w.fs && !dropout_on(m)) ? gmc_lds_groups(b, m->F) : 1;   // (dropout: Z0 comes from its own kernel)
     const size_t cols = w.fs ? (F + w.fs - 1) / w.fs * w.fs : (size_t)w.ld;
     w.T0 = take(R * cols);
     w.H = take(R * cols);
@@ -94,6 +101,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
         w.part = take(tiles * F * 4);
         w.db2part = take((size_t)b->B * 3);
         w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
+        if (dropout_on(m)) w.W2s = take(F * 3);
     }
     w.bytes = off;
     return w;
@@ -106,6 +114,7 @@ int check(const gmc_batch *b, const gmc_model *m) {
     if (m->K != 3) return GMC_ERR_CLASSES;
     if (b->B < 0 || b->R < 0 || b->nnz < 0 || m->N <= 0 || m->F <= 0) return GMC_ERR_SHAPE;
     if (m->F % 4 || m->F > 1024) return GMC_ERR_UNSUPPORTED;  // float4 rows, <= 4 passes per lane
+    if (!(m->dropout_p >= 0.f && m->dropout_p < 1.f)) return GMC_ERR_SHAPE;
     if (b->B > 0 && (b->n_max < 3 || b->n_max > GMC_MAX_GRAPH_NODES)) return GMC_ERR_GRAPH_SIZE;
     if (b->n_max > m->N) return GMC_ERR_SHAPE;  // more nodes than rows of conv1.weight
     return GMC_OK;
@@ -126,7 +135,7 @@ int aggregate(const gmc_batch *b, const Workspace &w, const float *X, float *Y, 
 
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
     const int F = m->F;
-    if (w.fs && fuse_enabled())  // T0 lives only in LDS
+    if (w.fs && fuse_enabled() && !dropout_on(m))  // T0 lives only in LDS
         return gmc_fwd1_lds_launch(b, m->W1, m->b1, m->W2, w.H, w.Z0, F, st);
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
     int rc = w.fs ? gmc_spmm_lds_launch(b, m->W1, F, 0, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, 1, F, nullptr,
@@ -134,6 +143,13 @@ int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hip
                   : gmc_spmm_launch(b->rowptr, b->lcol, b->vals, b->dinv, m->W1, F, nullptr, 0, w.T0, w.ld,
                                     b->R, F, group_rows(b), nullptr, nullptr, GMC_K_GATHER_W1, st);
     if (rc) return rc;
+    if (dropout_on(m)) {  // relu -> dropout -> layer-2 feature transform of the DROPPED activations (:81-83)
+        rc = aggregate(b, w, w.T0, w.H, F, m->b1, 1, nullptr, nullptr, GMC_K_AGG_FWD, st);
+        if (rc) return rc;
+        rc = gmc_dropout_launch(w.H, b->R, F, w.fs, w.ld, m->dropout_p, dropout_seed(m), st);
+        if (rc) return rc;
+        return gmc_hw2_rows_launch(w.H, b->dinv, m->W2, w.Z0, b->R, F, w.fs, w.ld, st);
+    }
     // layer 1 aggregation + bias + relu with the layer 2 feature transform fused in
     return aggregate(b, w, w.T0, w.H, F, m->b1, 1, m->W2, w.Z0, GMC_K_AGG_FWD, st);
 }
@@ -150,7 +166,14 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
-    if (w.fs && fuse_enabled() && gmc_bwd1_fits(b)) {  // one pass over H: Gs and U live only in LDS
+    const float *W2b = m->W2;
+    if (dropout_on(m)) {  // relu'(H) o mask / (1-p): the mask is the zeros of the stored H, the factor rides on W2
+        if (af || !w.W2s) return GMC_ERR_UNSUPPORTED;
+        int rc = gmc_scale_copy_launch(m->W2, w.W2s, (int)F * 3, 1.0f / (1.0f - m->dropout_p), st);
+        if (rc) return rc;
+        W2b = w.W2s;
+    }
+    if (w.fs && fuse_enabled() && gmc_bwd1_fits(b) && !dropout_on(m)) {  // one pass over H: Gs and U live only in LDS
         const int chunks = gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, m->F)), per = (b->B + chunks - 1) / chunks;
         int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
         if (rc) return rc;
@@ -160,8 +183,8 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
                                  af ? af->step_counter : nullptr, loss_tail, st);
     }
     if (af) return GMC_ERR_UNSUPPORTED;  // the fused Adam rides on the fused backward
-    int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, m->W2, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
-                  : gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, m->W2, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
+    int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, W2b, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
+                  : gmc_hidden_bwd_launch(w.H, w.ld, w.GY2, W2b, b->dinv, Gs, w.ld, w.part, b->R, m->F, st);
     if (rc) return rc;
     rc = gmc_colsum_reduce_launch(w.part, w.fs ? gmc_hidden_slab_tiles(b->R) : gmc_hidden_tiles(b->R), m->F,
                                   dW2, db1, w.db2part, b->B, db2, st);
@@ -308,7 +331,7 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     if (!param || !grad || !mom || !var || !step_counter) return GMC_ERR_NULL;
     if (!gmc_aligned16(param) || !gmc_aligned16(mom) || !gmc_aligned16(var)) return GMC_ERR_ALIGN;
     const long nW1 = (long)N * F;
-    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3};
+    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3, 0.f, 0u, 0u};
     int rc = check(batch, &model);
     if (rc) return rc;
     if (!P || !workspace) return GMC_ERR_NULL;

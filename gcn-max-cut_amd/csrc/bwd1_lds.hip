@@ -2,6 +2,12 @@
 // for graphs that fit a CU's LDS.  Shared tile machinery: lds_tile.h.
 #include "lds_tile.h"
 
+#ifdef GMC_STAMP
+extern "C" int gmc_debug_read_stamps_bwd(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
+
 namespace {
 
 // ---- fused layer-1 backward: hidden backward + aggregation + dW1 in one pass over H --------

@@ -3,8 +3,7 @@
 #include "lds_tile.h"
 
 #ifdef GMC_STAMP
-__device__ unsigned long long g_stamps[4096 * 16];
-extern "C" int gmc_debug_read_stamps(unsigned long long *out, int n) {
+extern "C" int gmc_debug_read_stamps_fwd(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
 }
 #endif

@@ -11,7 +11,7 @@
 // (never read by any kernel); gmc_debug_read_stamps copies them out.  The production library
 // contains none of this.
 #ifdef GMC_STAMP
-extern __device__ unsigned long long g_stamps[4096 * 16];  // defined in fwd1_lds.hip
+static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per translation unit (no device linking)
 #define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {}
 #define STAMP(i)                                                     \
     do {                                                             \

@@ -64,6 +64,23 @@ class FusedEngine:
                                    W1=hip.ptr(v["conv1.weight"]), b1=hip.ptr(v["conv1.bias"]),
                                    W2=hip.ptr(v["conv2.weight"]), b2=hip.ptr(v["conv2.bias"]))
 
+    def set_dropout(self, p: float, seed: Optional[int] = None) -> None:
+        """F.dropout between the layers (TrainingNeural.py:82) for the next forward / training calls:
+        ``p`` = 0 switches it off (eval mode, every reference configuration).  ``seed`` = None draws one
+        from torch's CPU generator, so ``torch.manual_seed`` makes runs repeatable (the mask itself is the
+        library's counter-based hash, not torch's random stream)."""
+        p = float(p)
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), got {p}")
+        if p > 0.0 and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self._model.dropout_p = p
+        self._model.dropout_seed_lo = (seed or 0) & 0xFFFFFFFF
+        self._model.dropout_seed_hi = ((seed or 0) >> 32) & 0xFFFFFFFF
+
+    def dropout_state(self) -> Tuple[float, int]:
+        return float(self._model.dropout_p), (int(self._model.dropout_seed_hi) << 32) | int(self._model.dropout_seed_lo)
+
     def adopt(self, module: torch.nn.Module) -> None:
         """Make ``module.conv{1,2}.{weight,bias}`` views of the flat buffer (values kept)."""
         named = dict(module.named_parameters())

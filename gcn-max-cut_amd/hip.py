@@ -44,6 +44,7 @@ class GmcModel(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
+        ("dropout_p", C.c_float), ("dropout_seed_lo", C.c_uint32), ("dropout_seed_hi", C.c_uint32),
     ]
 
 

@@ -77,6 +77,14 @@ typedef struct gmc_model {
     int32_t N, F, K;
     int32_t flags; /* GMC_MODEL_* bits, 0 by default */
     const float *W1, *b1, *W2, *b2;
+    /* F.dropout(h, p, training) between the layers (TrainingNeural.py:82; TrainingConfig.dropout :43).
+     * 0 = identity: eval mode, and every reference configuration.  With p in (0,1) the entry points that
+     * take a gmc_model apply H <- H o mask / (1-p) after relu, mask from a counter-based hash of
+     * (dropout_seed, row, column) - reproducible from the seed, not torch's random stream - and run the
+     * one-kernel-per-operation sequence.  gmc_backward_from_gp must be given the same p (and the workspace)
+     * as the gmc_forward that produced P.  gmc_train_step_f32 has no dropout (it builds its own model). */
+    float dropout_p;
+    uint32_t dropout_seed_lo, dropout_seed_hi;
 } gmc_model;
 /* gmc_train_fwd_bwd: grad has ONE more float after the N*F + F + F*3 + 3 gradient entries and
  * receives the sum of the batch's per-graph losses there (loss must be non-NULL).  Lets a

@@ -9,19 +9,19 @@ batch = pkg.GraphBatch(hs, None)
 net, _, _ = T.setup_model_and_optimizer(T.TrainingConfig(n_nodes=1000, hidden_dim=F))
 eng = net.engine(); lib = pkg.hip.load()
 names = {"fwd": ["loop", "dma_wait", "barrier1", "gather1", "barrier2", "stores+dma", "gather2"],
-         "bwd": ["loop", "transform", "barrierA", "gather1", "barrierB", "fetch", "gather2", "dma_wait", "barrierC", "commit", "barrierD"]}
-def read(nblk):
+         "bwd": ["loop", "transform+consts_dma", "barrierA", "gather1+consts_wait", "barrierB", "tile_dma_issue", "gather2", "tile_dma_wait", "-", "next_ids", "-"]}
+def read(nblk, which):
     buf = (C.c_ulonglong * (nblk * 16))()
-    rc = lib.gmc_debug_read_stamps(buf, nblk * 16); assert rc == 0
+    rc = getattr(lib, "gmc_debug_read_stamps_" + which)(buf, nblk * 16); assert rc == 0
     return np.frombuffer(buf, dtype=np.uint64).reshape(nblk, 16).astype(np.float64)
 for _ in range(3): eng.train_fwd_bwd(batch)
 torch.cuda.synchronize()
 # forward only -> stamps of fwd1 (grid 1280)
 eng.forward(batch); torch.cuda.synchronize()
-a = read(256)
+a = read(256, 'fwd')
 tot = a[:, :12].sum(1).mean()
 print("fwd1 cycles per WG %.0f" % tot, {k: round(100 * a[:, i].mean() / tot, 1) for i, k in enumerate(names["fwd"])}, "epilogue %.1f prologue %.1f" % (100 * a[:, 7].mean() / tot, 100 * a[:, 11].mean() / tot))
 eng.train_fwd_bwd(batch); torch.cuda.synchronize()
-b = read(256)
+b = read(256, 'bwd')
 tot = b[:, :11].sum(1).mean()
 print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})
