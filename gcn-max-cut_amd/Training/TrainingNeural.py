@@ -335,6 +335,8 @@ class FusedTrainer:
         self._plan_key = None
         self._ws: Optional[torch.Tensor] = None   # scratch of this trainer's steps (captured graphs point into it)
         self._graph_key = None
+        self._graph_env = None
+        self._poll = os.environ.get("GCN_MAXCUT_POLL_LOSS", "1") != "0"   # watch the pinned loss slots instead of a stream sync
         self._dp_graph = None       # (per-step forward/backward hipGraphs, Adam hipGraph) of a data-parallel rank
         self._dp_graph_key = None
         self.allow_graph = True     # set False to force eager launches (per-kernel probing)
@@ -347,12 +349,17 @@ class FusedTrainer:
         self._out = None
 
     def prepare(self, dataset: Dict) -> None:
-        items = list(dataset.values())
-        # (handles and adjacency tensors by identity + in-place version: a dataset edited in place is re-planned)
-        key = (id(dataset), self.graphs_per_step, self.world,
-               tuple((id(it[0]), id(it[1]), getattr(it[1], "_version", 0)) for it in items))
+        # O(1) per epoch: the dict, its size, and its first / last items by identity + in-place version of their
+        # adjacency (an item replaced or edited in place re-plans; the full walk happens only then)
+        probe = None
+        if dataset:
+            first = next(iter(dataset.values()))
+            last = dataset[next(reversed(dataset))] if hasattr(dataset, "__reversed__") else first
+            probe = tuple((id(it[0]), id(it[1]), getattr(it[1], "_version", 0)) for it in (first, last))
+        key = (id(dataset), len(dataset), self.graphs_per_step, self.world, probe)
         if key == self._plan_key:
             return
+        items = list(dataset.values())
         gps, dev = self.graphs_per_step, self.eng.device
         self._batches = []
         stride = gps if self.local_shard else gps * self.world
@@ -372,6 +379,7 @@ class FusedTrainer:
         # kernels (inside the replayed hipGraph on one GPU), the host then waits on one event
         self._loss_host = (torch.empty_like(self._loss_slots, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
+        self._loss_host_np = self._loss_host.numpy() if self._loss_host is not None else None   # (shares the pinned memory)
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         # private scratch, sized for the largest step: the engine's own scratch is re-allocated whenever a
@@ -408,8 +416,6 @@ class FusedTrainer:
         self.prepare(dataset)
         eng, cfg = self.eng, self.config
         drop = self._dropout()
-        if hasattr(eng, "set_dropout") and drop == 0.0:
-            eng.set_dropout(0.0)
         if drop > 0.0:
             # dropout: eager launches of the one-kernel-per-operation sequence, a fresh mask per step (the
             # captured graphs would replay one mask; every reference configuration trains with p = 0)
@@ -427,10 +433,14 @@ class FusedTrainer:
                 eng.adam_step(lr, betas, eps)
             eng.set_dropout(0.0)
             return float(self._step_loss.cpu().numpy().sum(dtype=np.float64))
-        if self._use_graph():
+        use_graph = self._use_graph()
+        poll = use_graph and self._poll and self._loss_host_np is not None
+        if poll:
+            self._loss_host_np.fill(np.nan)   # sentinel: every loss is a finite number (<= 0)
+        if use_graph:
             self._replay_epoch()
         elif self.world == 1 and hasattr(eng, "train_step"):
-            eng.step_dev.fill_(eng.step_count)
+            eng.sync_step_dev()
             self._enqueue_epoch()
         else:
             # the step's loss rides in the gradient all-reduce: train_fwd_bwd leaves the shard's loss sum
@@ -440,7 +450,7 @@ class FusedTrainer:
             lr, betas, eps = self._hyper()
             graphs = self._dp_graphs() if self._use_dp_graph() else None
             if graphs is not None:
-                eng.step_dev.fill_(eng.step_count)
+                eng.sync_step_dev()
             for i, batch in enumerate(self._batches):
                 if batch.B == 0:
                     # this rank's shard of the step is empty (last group smaller than the world): it
@@ -459,6 +469,7 @@ class FusedTrainer:
                 if graphs is not None:
                     graphs[1].replay()                 # Adam, step number read from / advanced in device memory
                     eng.step_count += 1
+                    eng._dev_step += 1
                 else:
                     eng.adam_step(lr, betas, eps)
         if self.world > 1:   # one host sync per epoch
@@ -477,24 +488,57 @@ class FusedTrainer:
         # one device->host copy per epoch; the reference adds one float per optimizer step
         # (loss.item(), :388), each the sum of that step's per-graph losses
         if self._loss_host is not None:
-            if not self._use_graph():   # (the replayed graph ends with this copy)
+            if not use_graph:   # (the replayed graph ends with this copy)
                 self._loss_host.copy_(self._loss_slots, non_blocking=True)
+            host = self._loss_host_np
+            if poll:
+                return self._wait_for_losses(host)
             torch.cuda.current_stream().synchronize()
-            host = self._loss_host.numpy()
         else:
             host = self._loss_slots.cpu().numpy()
+        if len(self._batches) == 1:
+            return float(host[0, :self._batches[0].B].sum(dtype=np.float32))
         total = 0.0
         for i, batch in enumerate(self._batches):
             total += float(host[i, :batch.B].sum(dtype=np.float32))
+        return total
+
+    def _wait_for_losses(self, host: np.ndarray) -> float:
+        """The replayed graph ends with the copy of the per-graph losses into pinned host memory: the host
+        watches that memory instead of sleeping in hipStreamSynchronize (whose wake-up costs ~10 us per step
+        of a 0.25 ms step).  The slots were filled with NaN before the launch; a step's sum is taken once
+        its first and last slot have landed and is accepted when it is a number (a slot still missing makes
+        it NaN).  A sentinel that does not go away within seconds hands over to the stream synchronisation,
+        which reports whatever went wrong on the device.  Returns the epoch's cumulative loss."""
+        total, deadline = 0.0, None
+        for i, batch in enumerate(self._batches):
+            nb = batch.B
+            if nb == 0:
+                continue
+            row, spins = host[i], 0
+            while True:
+                if row[nb - 1] == row[nb - 1] and row[0] == row[0]:      # (x == x: not NaN)
+                    step = float(row[:nb].sum(dtype=np.float32))
+                    if step == step:
+                        total += step
+                        break
+                spins += 1
+                if spins & 0xFFF == 0:
+                    now = time()
+                    deadline = deadline or now + 5.0
+                    if now > deadline:
+                        torch.cuda.current_stream().synchronize()
+                        deadline = now + 1e9   # (if the device is fine the values are there now; keep looking)
         return total
 
     def _use_graph(self) -> bool:
         """On one GPU an epoch's launches (the reference's one Adam step per graph: hundreds of
         ~10 us kernels; or one batched step: six) are captured once into a hipGraph and replayed per
         epoch, which removes the per-launch host cost."""
-        return (self.allow_graph and self.world == 1 and len(self._batches) >= 1
-                and hasattr(self.eng, "train_step")
-                and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
+        if self._graph_env is None:   # process-wide facts, looked up once
+            self._graph_env = torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0"
+        return (self.allow_graph and self.world == 1 and self._graph_env and len(self._batches) >= 1
+                and hasattr(self.eng, "train_step"))
 
     def _use_dp_graph(self) -> bool:
         """Data-parallel ranks: the launches on either side of the (eager) all-reduce are replayed from
@@ -521,14 +565,15 @@ class FusedTrainer:
                 eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws)
             fb.append(g)
         before, flat, m, v = eng.step_count, eng.flat.clone(), eng.m.clone(), eng.v.clone()
-        eng.step_dev.fill_(eng.step_count)
+        eng.sync_step_dev()
         eng.adam_step_dev(lr, betas, eps)                              # eager once (state restored below)
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
             eng.adam_step_dev(lr, betas, eps)
         eng.flat.copy_(flat); eng.m.copy_(m); eng.v.copy_(v)
         eng.step_count = before
-        eng.step_dev.fill_(before)
+        eng._dev_step = -1                                             # (the capture pass counted on the host only)
+        eng.sync_step_dev()
         self._dp_graph, self._dp_graph_key = (fb, ga), key
         return self._dp_graph
 
@@ -543,7 +588,7 @@ class FusedTrainer:
 
     def _replay_epoch(self) -> None:
         eng = self.eng
-        eng.step_dev.fill_(eng.step_count)
+        eng.sync_step_dev()   # (no launch while this trainer's replays are the only thing stepping the optimizer)
         # the captured launches carry lr / betas / eps / C and the scratch pointer as kernel arguments
         key = (self._hyper(), float(self.config.C), self._ws.data_ptr() if self._ws is not None else 0)
         if self._graph is not None and key != self._graph_key:
@@ -555,12 +600,13 @@ class FusedTrainer:
             before = eng.step_count
             with torch.cuda.graph(graph):
                 self._enqueue_epoch(with_readback=True)
-            eng.step_count = before               # capture enqueued nothing
+            eng.step_count = eng._dev_step = before   # capture enqueued nothing
             self._graph, self._graph_steps = graph, len(self._batches)
             self._loss_host.copy_(self._loss_slots, non_blocking=True)   # this (eager) epoch's losses
             return
         self._graph.replay()
         eng.step_count += self._graph_steps
+        eng._dev_step += self._graph_steps
 
     def sync_optimizer_state(self) -> None:
         """Expose step / exp_avg / exp_avg_sq of the fused Adam through ``optimizer.state``."""

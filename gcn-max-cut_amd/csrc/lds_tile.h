@@ -258,8 +258,19 @@ int pick_fs(int n_max, int W) {
 
 template <typename K, typename A>
 int launch(K k, int grid, size_t lds, hipStream_t st, const A &args) {
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 64 * 1024) {
+        // the large-LDS opt-in is per kernel, not per launch: remember which kernels have it (a launch is
+        // otherwise two runtime calls; single-threaded callers per process, as everywhere in this library)
+        static const void *configured[256];
+        static int n_configured = 0;
+        const void *fn = reinterpret_cast<const void *>(k);
+        bool seen = false;
+        for (int i = 0; i < n_configured; ++i) seen |= configured[i] == fn;
+        if (!seen) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (n_configured < 256) configured[n_configured++] = fn;
+        }
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), lds, st, args);
     GMC_LAUNCH_CHECK();
     return GMC_OK;

@@ -43,6 +43,10 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
+    // the counted vmcnt wait of the slice loop needs every WAVE to issue exactly ACC store instructions per
+    // slice: a wave holds 64 / Q whole rows, i.e. every column group of the slice, and group 0 is always in
+    // range - so no wave can be left without an active lane on the last (partial) slice
+    static_assert(Q <= 64 && 64 % Q == 0, "a wave must hold whole rows of the tile");
     int g, grp;
     tile_of((int)blockIdx.x, a.b.B, a.groups, g, grp);
     const int r0 = a.b.goff[g];

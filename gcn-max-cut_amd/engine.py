@@ -47,6 +47,7 @@ class FusedEngine:
         self.v = torch.zeros_like(self.flat)
         self.step_count = 0
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)  # device mirror of step_count
+        self._dev_step = 0   # what step_dev holds (host shadow): replayed / device-stepped launches advance both
         self._ws: Optional[torch.Tensor] = None
         self._model = hip.GmcModel()
         self._refresh_model()
@@ -164,6 +165,7 @@ class FusedEngine:
                                          hip.stream())
         hip.check(rc, "gmc_train_step_f32")
         self.step_count += 1
+        self._dev_step += 1
         return P, S, loss
 
     def backward_from_gp(self, batch: GraphBatch, P: torch.Tensor, GP: torch.Tensor,
@@ -194,6 +196,14 @@ class FusedEngine:
                                            hip.ptr(self.step_dev), hip.stream())
         hip.check(rc, "gmc_adam_devstep_f32")
         self.step_count += 1
+        self._dev_step += 1
+
+    def sync_step_dev(self) -> None:
+        """Make the device-side step counter equal ``step_count`` - a fill launch only when they differ
+        (after host-stepped Adam launches); a trainer replaying its graph epoch after epoch never needs it."""
+        if self._dev_step != self.step_count:
+            self.step_dev.fill_(self.step_count)
+            self._dev_step = self.step_count
 
     def sync_replicas(self, src: int = 0) -> None:
         """Data-parallel start-up: every rank takes rank ``src``'s parameters, Adam moments and step
@@ -206,7 +216,8 @@ class FusedEngine:
         step = torch.tensor([self.step_count], dtype=torch.int64, device=self.device)
         dist.broadcast(step, src)
         self.step_count = int(step.item())
-        self.step_dev.fill_(self.step_count)
+        self._dev_step = -1
+        self.sync_step_dev()
 
     def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""

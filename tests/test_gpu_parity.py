@@ -631,7 +631,7 @@ def test_adam_parity_step_by_step_on_the_reference_schedule(pkg):
         ct.m[:] = eng.m[:eng.count].cpu().numpy()
         ct.v[:] = eng.v[:eng.count].cpu().numpy()
         ct.t = t - 1
-        eng.step_dev.fill_(eng.step_count)
+        eng.sync_step_dev()
         _, _, loss = eng.train_step(batch, cfg.learning_rate, cfg.C)
         ref_loss = ct.step([csr])
         assert eng.step_count == t == ct.t
