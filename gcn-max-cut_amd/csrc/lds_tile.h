@@ -51,8 +51,13 @@ namespace {
 #define GMC_LDS_THREADS 1024
 #endif
 constexpr int kThreads = GMC_LDS_THREADS;
-// 4 waves per SIMD either way (1 x 1024 or 2 x 512 threads per CU): 128 VGPRs per lane
-#define GMC_LDS_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// waves per SIMD the register allocation is sized for: 4 (128 VGPRs per lane) for one 1024-thread workgroup
+// per CU; GMC_LDS_WAVES_PER_EU overrides (tuning builds: 512 threads with 2 = 256 VGPRs, or 4 for two
+// co-resident workgroups)
+#ifndef GMC_LDS_WAVES_PER_EU
+#define GMC_LDS_WAVES_PER_EU 4
+#endif
+#define GMC_LDS_BOUNDS __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(GMC_LDS_WAVES_PER_EU, GMC_LDS_WAVES_PER_EU)))
 
 struct TileArgs {
     gmc_batch b;
