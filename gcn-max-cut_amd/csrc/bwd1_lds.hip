@@ -143,7 +143,7 @@ __device__ __forceinline__ void dma_row_consts(const float *GY2, int r0, int n, 
 //   (Tried and dropped, measured same-box: pulling the H tile of graph g+2 into L2 with 4-byte LDS-DMA
 //   touches while the tile of g+1 streams in, so that the DMA runs at L2 latency - the kernel got 11 %
 //   SLOWER; the tile DMA's only shadow stays gather #2.)
-template <int FS, int ACC, bool HAS_VAL>
+template <int FS, int ACC, bool HAS_VAL, int NS>
 __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W = 8;
@@ -224,7 +224,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
-            float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false>(bufA, idr[k], nullptr, q);
+            float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
         }
@@ -242,8 +242,8 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
-            if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true>(bufB, idr[k], wbase + (long)l * W, q));
-            else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS>(bufB, idr[k], q);
+            if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
+            else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
             // the sum is needed HERE (its only user is the store after the graph loop: left alone the
             // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
             asm volatile("" : "+v"(acc[k]));
@@ -379,10 +379,15 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     const int grid = a.slices * a.chunks;
     const bool hv = a.b.ell_vals != nullptr;
     if constexpr (W == 8) {
-        if (acc <= 4) return hv ? launch(bwd1_reg_kernel<FS, 4, true>, grid, lds, st, a)
-                                : launch(bwd1_reg_kernel<FS, 4, false>, grid, lds, st, a);
-        if (acc <= 8) return hv ? launch(bwd1_reg_kernel<FS, 8, true>, grid, lds, st, a)
-                                : launch(bwd1_reg_kernel<FS, 8, false>, grid, lds, st, a);
+        if (a.b.ell_slots == 7 && !hv) {  // no row of the batch has more than 7 neighbours: slot 7 is skipped
+            if (acc <= 4) return launch(bwd1_reg_kernel<FS, 4, false, 7>, grid, lds, st, a);
+            if (acc <= 8) return launch(bwd1_reg_kernel<FS, 8, false, 7>, grid, lds, st, a);
+            return GMC_ERR_UNSUPPORTED;
+        }
+        if (acc <= 4) return hv ? launch(bwd1_reg_kernel<FS, 4, true, 8>, grid, lds, st, a)
+                                : launch(bwd1_reg_kernel<FS, 4, false, 8>, grid, lds, st, a);
+        if (acc <= 8) return hv ? launch(bwd1_reg_kernel<FS, 8, true, 8>, grid, lds, st, a)
+                                : launch(bwd1_reg_kernel<FS, 8, false, 8>, grid, lds, st, a);
     } else {
         if (acc <= 4) return hv ? launch(bwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
                                 : launch(bwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);

@@ -24,8 +24,9 @@ const int kQuad[4][4] = {{0, 3, 5, 6}, {1, 2, 4, 7}, {8, 11, 13, 14}, {9, 10, 12
 
 struct Nbr { int id; float w; };
 
+// NS <= W: slots that may hold a neighbour (slots NS..W-1 of every row become padding)
 void arrange_quad(const int rows[4], int nrows_valid, const int32_t *rowptr, const int32_t *lcol, const float *vals,
-                  int r0, int n, int W, uint16_t *ell, float *ell_vals) {
+                  int r0, int n, int W, int NS, uint16_t *ell, float *ell_vals) {
     std::vector<Nbr> byc[4][4];  // [row][colour] remaining neighbours (taken from the back)
     int rem[4] = {0, 0, 0, 0};
     for (int i = 0; i < 4; ++i) {
@@ -39,8 +40,16 @@ void arrange_quad(const int rows[4], int nrows_valid, const int32_t *rowptr, con
     }
     (void)nrows_valid;
     int perm[4] = {0, 1, 2, 3};
-    for (int u = 0; u < W; ++u) {
-        const int left = W - u;  // slots still to fill, this one included
+    for (int u = NS; u < W; ++u) {  // the slots the kernels skip
+        for (int i = 0; i < 4; ++i) {
+            if (rows[i] < 0) continue;
+            const long slot = (long)(r0 + rows[i]) * W + u;
+            ell[slot] = (uint16_t)(n + (i & 3));
+            if (ell_vals) ell_vals[slot] = 0.0f;
+        }
+    }
+    for (int u = 0; u < NS; ++u) {
+        const int left = NS - u;  // slots still to fill, this one included
         int D[4] = {0, 0, 0, 0};  // remaining demand per colour
         for (int i = 0; i < 4; ++i)
             for (int c = 0; c < 4; ++c) D[c] += (int)byc[i][c].size();
@@ -78,16 +87,56 @@ void arrange_quad(const int rows[4], int nrows_valid, const int32_t *rowptr, con
             }
         }
     }
+    // Refinement.  The slot-by-slot pass above leaves its conflicts to the last slots; without padding to
+    // absorb them (7 live slots, every row full) they pile up there.  Hill-climb over swaps of two slots
+    // inside one row: only those two slots' costs change; cost of a slot = LDS cycles of its fetch = the
+    // largest number of DISTINCT rows of one quarter among the group's ids.
+    auto slot_cost = [&](int u) {
+        int ids[4], k = 0, cnt[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) {
+            if (rows[i] < 0) continue;
+            const int id = ell[(long)(r0 + rows[i]) * W + u];
+            bool dup = false;
+            for (int j = 0; j < k; ++j) dup |= ids[j] == id;   // identical addresses broadcast
+            if (!dup) { ids[k++] = id; ++cnt[id & 3]; }
+        }
+        return std::max(std::max(cnt[0], cnt[1]), std::max(cnt[2], cnt[3]));
+    };
+    for (int pass = 0, improved = 1; pass < 8 && improved; ++pass) {
+        improved = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (rows[i] < 0) continue;
+            const long base = (long)(r0 + rows[i]) * W;
+            for (int u = 0; u < NS; ++u)
+                for (int v = u + 1; v < NS; ++v) {
+                    if ((ell[base + u] & 3) == (ell[base + v] & 3)) continue;  // same quarter: nothing changes
+                    const int before = slot_cost(u) + slot_cost(v);
+                    std::swap(ell[base + u], ell[base + v]);
+                    if (ell_vals) std::swap(ell_vals[base + u], ell_vals[base + v]);
+                    if (slot_cost(u) + slot_cost(v) < before) { improved = 1; continue; }
+                    std::swap(ell[base + u], ell[base + v]);
+                    if (ell_vals) std::swap(ell_vals[base + u], ell_vals[base + v]);
+                }
+        }
+    }
 }
 
 }  // namespace
 
 // All pointers are HOST pointers.  ell: [R][W] (W = 8 or 16, >= max degree), ell_vals: [R][W] or NULL.
 // Padding entries are n_g .. n_g+3 (four all-zero tile rows, one per bank quarter).
+extern "C" int gmc_ell_slots_for(int32_t R, const int32_t *rowptr, int32_t W) {
+    if (W != 8 || !rowptr) return W;
+    int top = 0;
+    for (int r = 0; r < R; ++r) top = std::max(top, rowptr[r + 1] - rowptr[r]);
+    return top <= 7 ? 7 : 8;
+}
+
 extern "C" int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_t *rowptr, const int32_t *lcol,
                                     const float *vals, int32_t W, uint16_t *ell, float *ell_vals) {
     if (!goff || !rowptr || !lcol || !ell) return GMC_ERR_NULL;
     if (B < 0 || (W != 8 && W != 16)) return GMC_ERR_SHAPE;
+    const int NS = B > 0 ? gmc_ell_slots_for(goff[B], rowptr, W) : W;
     for (int g = 0; g < B; ++g) {
         const int r0 = goff[g], n = goff[g + 1] - r0;
         if (n + 4 > 65535) return GMC_ERR_GRAPH_SIZE;
@@ -101,7 +150,7 @@ extern "C" int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_
                     rows[i] = l < n ? l : -1;
                     valid += l < n;
                 }
-                if (valid) arrange_quad(rows, valid, rowptr, lcol, vals, r0, n, W, ell, ell_vals);
+                if (valid) arrange_quad(rows, valid, rowptr, lcol, vals, r0, n, W, NS, ell, ell_vals);
             }
         }
     }

@@ -19,7 +19,7 @@ namespace {
 // H = relu(dinv o (A @ T0) + b1) (:80-81) from B, with the layer-2 feature transform
 // (H o dinv) @ W2 (:83) accumulated in registers.  T0 never exists in HBM: the forward of layer 1
 // writes H once and reads only W1 (from L2) and the neighbour table.
-template <int FS, int W, int ACC, bool HAS_VAL>
+template <int FS, int W, int ACC, bool HAS_VAL, int NS>
 __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     STAMP_DECL;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -138,7 +138,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
                     const int lc = min(l, n - 1);
                     float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
-                                      : gather_ids8<FS, HAS_VAL>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                                      : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -147,7 +147,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                 for (int k = 0; k < ACC; ++k) {
                     const int l = lrow + k * kRowsPerPass;
                     if (l < n) {
-                        float4 t = gather_row<FS, W, HAS_VAL>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                        float4 t = gather_row<FS, W, HAS_VAL, NS>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
                         t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                         reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
                     }
@@ -195,9 +195,9 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                    emit(k, ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS>(bufB, cur, q));
+                    emit(k, ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q));
                 } else {
-                    emit(k, gmc::f4v(gather_row<FS, W, false>(bufB, nb, nullptr, l, q)));
+                    emit(k, gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q)));
                 }
             }
             STAMP(6);  // gather 2
@@ -213,10 +213,19 @@ template <int FS, int W>
 int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
     constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
-    if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
-                                    : launch(fwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
-    if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
-                                    : launch(fwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+    // 7 live slots (no row of the batch has more than 7 neighbours): unit-weight kernels skip slot 7
+    const bool s7 = W == 8 && a.b.ell_slots == 7 && !a.use_vals;
+    if constexpr (W == 8) {
+        if (s7) {
+            if (acc <= 4) return launch(fwd1_lds_kernel<FS, W, 4, false, 7>, grid, lds, st, a);
+            if (acc <= 8) return launch(fwd1_lds_kernel<FS, W, 8, false, 7>, grid, lds, st, a);
+            return GMC_ERR_UNSUPPORTED;
+        }
+    }
+    if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true, 8>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 4, false, 8>, grid, lds, st, a);
+    if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true, 8>, grid, lds, st, a)
+                                    : launch(fwd1_lds_kernel<FS, W, 8, false, 8>, grid, lds, st, a);
     return GMC_ERR_UNSUPPORTED;
 }
 

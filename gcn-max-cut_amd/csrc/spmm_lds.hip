@@ -38,7 +38,7 @@ namespace {
 //   LDS gather of slice s  ->  wait (loads s+1 done; stores s-1 long done)  ->
 //   write slice s+1 to the other LDS buffer  ->  barrier.
 // SHARED: the source is one table shared by every graph (W1 for the layer-1 feature transform)
-template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED>
+template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED, int NS = 8>
 __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -131,7 +131,7 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);
-            const float4 acc = gather_row<FS, W, HAS_VAL>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+            const float4 acc = gather_row<FS, W, HAS_VAL, NS>(tile, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
             // pad columns: the tile holds finite values there (see prefetch), scale 0 and bias 0 make
             // them exact zeros without a per-row select; relu / identity is one v_max either way
             const float sk = (EPI && !col_on) ? 0.f : sc[k];
@@ -196,7 +196,7 @@ struct Dw1TileArgs {
     int graphs_per_chunk;
 };
 
-template <int FS, int W, int ACC, bool HAS_VAL>
+template <int FS, int W, int ACC, bool HAS_VAL, int NS = 8>
 __global__ GMC_LDS_BOUNDS void dw1_lds_kernel(Dw1TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -251,7 +251,7 @@ __global__ GMC_LDS_BOUNDS void dw1_lds_kernel(Dw1TileArgs a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL>(lds + cur * TF, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+            if (l < n) gmc::f4_add(acc[k], gather_row<FS, W, HAS_VAL, NS>(lds + cur * TF, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
         }
         if (g + 1 < g1) {
             const int n1 = a.b.goff[g + 2] - a.b.goff[g + 1];
@@ -287,6 +287,16 @@ int launch_spmm(const TileArgs &a, size_t lds, hipStream_t st) {
         return epi ? launch(spmm_lds_kernel<FS, W, AC, true, false, false>, grid, lds, st, a)                 \
                    : launch(spmm_lds_kernel<FS, W, AC, false, false, false>, grid, lds, st, a);               \
     } while (0)
+    if constexpr (W == 8) {
+        // 7 live slots (no row of the batch has more than 7 neighbours): the unit-weight aggregation skips slot 7
+        if (a.b.ell_slots == 7 && !a.use_vals && !a.shared_src) {
+            if (acc <= 4) return epi ? launch(spmm_lds_kernel<FS, W, 4, true, false, false, 7>, grid, lds, st, a)
+                                     : launch(spmm_lds_kernel<FS, W, 4, false, false, false, 7>, grid, lds, st, a);
+            if (acc <= 8) return epi ? launch(spmm_lds_kernel<FS, W, 8, true, false, false, 7>, grid, lds, st, a)
+                                     : launch(spmm_lds_kernel<FS, W, 8, false, false, false, 7>, grid, lds, st, a);
+            return GMC_ERR_UNSUPPORTED;
+        }
+    }
     if (acc <= 4) GMC_PICK(4);
     if (acc <= 8) GMC_PICK(8);
 #undef GMC_PICK
@@ -299,6 +309,13 @@ int launch_dw1(const Dw1TileArgs &a, size_t lds, hipStream_t st) {
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
     const int grid = a.slices * a.chunks;
     const bool hv = a.b.ell_vals != nullptr;
+    if constexpr (W == 8) {
+        if (a.b.ell_slots == 7 && !hv) {
+            if (acc <= 4) return launch(dw1_lds_kernel<FS, W, 4, false, 7>, grid, lds, st, a);
+            if (acc <= 8) return launch(dw1_lds_kernel<FS, W, 8, false, 7>, grid, lds, st, a);
+            return GMC_ERR_UNSUPPORTED;
+        }
+    }
     if (acc <= 4) return hv ? launch(dw1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
                             : launch(dw1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
     if (acc <= 8) return hv ? launch(dw1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)

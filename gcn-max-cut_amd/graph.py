@@ -178,6 +178,7 @@ class BatchArrays:
         # ELL copy for the LDS-tiled kernels: W slots per row (8 or 16), neighbours in CSR order,
         # padded with the graph's node count (the id of the all-zero tile row) / weight 0
         ell = ell_vals = None
+        ell_slots = 0
         max_deg = int(degi.max()) if degi.size else 0
         W = 8 if max_deg <= 8 else 16
         if 0 < max_deg <= 16 and int(ns.max()) < 65535:
@@ -199,6 +200,8 @@ class BatchArrays:
                 go32 = goff.astype(np.int32)
                 rc = lib.gmc_ell_arrange_host(B, ptr(go32), ptr(rowptr), ptr(lcol), ptr(vals), W, ptr(ell), ptr(ell_vals))
                 hip.check(rc, "gmc_ell_arrange_host")
+                # 7 when no row of the batch has more than 7 neighbours: slot 7 of every row is then padding
+                ell_slots = int(lib.gmc_ell_slots_for(R, ptr(rowptr), W)) if hasattr(lib, "gmc_ell_slots_for") else 0
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
         self.nnz_max = int(nnzs.max()) if B else 0
@@ -206,6 +209,7 @@ class BatchArrays:
         self.sizes, self.goff = ns, goff
         self.rowptr, self.gcol, self.lcol, self.vals, self.dinv = rowptr, gcol, lcol, vals, dinv
         self.ell, self.ell_vals, self.ell_width = ell, ell_vals, (W if ell is not None else 0)
+        self.ell_slots = ell_slots if ell is not None else 0   # (without the library: CSR slot order, every slot live)
 
 
 class GraphBatch:
@@ -229,7 +233,7 @@ class GraphBatch:
             B=h.B, R=h.R, nnz=h.nnz, n_max=h.n_max, uniform_n=h.uniform_n, nnz_max=h.nnz_max,
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
             lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv),
-            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, reserved=0)
+            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, ell_slots=h.ell_slots)
 
     def ref(self):
         return C.byref(self.c)

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("GCN_MAXCUT_LIB") or os.path.join(_PKG, "lib", "libgcn
 SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
-    "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_train_step_f32",
+    "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_ell_slots_for", "gmc_train_step_f32",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -36,7 +36,7 @@ class GmcBatch(C.Structure):
         ("uniform_n", C.c_int32), ("nnz_max", C.c_int32),
         ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
         ("vals", C.c_void_p), ("dinv", C.c_void_p),
-        ("ell", C.c_void_p), ("ell_vals", C.c_void_p), ("ell_width", C.c_int32), ("reserved", C.c_int32),
+        ("ell", C.c_void_p), ("ell_vals", C.c_void_p), ("ell_width", C.c_int32), ("ell_slots", C.c_int32),
     ]
 
 
@@ -67,6 +67,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_backward_from_gp.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), vp, sz, vp, vp, vp, vp]
     lib.gmc_adam_devstep_f32.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.gmc_ell_arrange_host.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp]
+    if hasattr(lib, "gmc_ell_slots_for"):   # (absent from libraries built before round 2: A/B runs load those)
+        lib.gmc_ell_slots_for.argtypes = [i32, vp, i32]
     lib.gmc_train_step_f32.argtypes = [C.POINTER(GmcBatch), i32, i32, vp, f32, vp, sz, vp, vp, vp, vp, vp, vp,
                                        C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.gmc_set_fuse.argtypes = [C.c_int]
@@ -74,6 +76,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_probe_begin.argtypes = [i32]
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
     for name in SYMBOLS:
+        if name == "gmc_ell_slots_for" and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes"):
             fn.restype = C.c_int

@@ -68,7 +68,11 @@ typedef struct gmc_batch {
     const uint16_t *ell;   /* [R][W] */
     const float *ell_vals; /* [R][W] or NULL when all ones */
     int32_t ell_width;
-    int32_t reserved;
+    /* neighbour slots that can hold a neighbour: 0 or ell_width = all of them; 7 (ell_width 8 only) = slot 7
+     * of EVERY row is padding, which is how gmc_ell_arrange_host lays out a batch whose largest degree is
+     * <= 7 (d = 7 regular graphs, the headline workload) - the LDS-tiled kernels then neither read nor add
+     * that slot.  (Was `reserved`, 0.) */
+    int32_t ell_slots;
 } gmc_batch;
 
 /* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):
@@ -99,9 +103,13 @@ const char *gmc_error_string(int code);
  * its CSR.  Inside each group of four rows that share an LDS cycle of the tiled kernels the
  * neighbours are ordered over the W slots so that a slot's four fetches fall into different LDS
  * bank quarters where possible; padding entries are n_g .. n_g+3 (four all-zero tile rows).
- * The slot order is the summation order of the LDS-tiled kernels (fixed per batch). */
+ * The slot order is the summation order of the LDS-tiled kernels (fixed per batch).  With W == 8 and no
+ * row of the batch longer than 7 the neighbours are arranged over slots 0..6 and slot 7 of every row is
+ * padding: set gmc_batch.ell_slots = 7 for such a batch (gmc_ell_slots_for tells). */
 int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_t *rowptr, const int32_t *lcol,
                          const float *vals, int32_t W, uint16_t *ell, float *ell_vals);
+/* the slots gmc_ell_arrange_host uses for a batch with R rows (host pointer): 7 or W */
+int gmc_ell_slots_for(int32_t R, const int32_t *rowptr, int32_t W);
 
 /* Kernel tags reported by the timing probe (one per launch of the fused step). */
 enum {
