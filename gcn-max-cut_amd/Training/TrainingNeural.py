@@ -382,6 +382,7 @@ class FusedTrainer:
         self._loss_host_np = self._loss_host.numpy() if self._loss_host is not None else None   # (shares the pinned memory)
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
+        self._step_host_np = self._step_host.numpy() if self._step_host is not None else None
         # private scratch, sized for the largest step: the engine's own scratch is re-allocated whenever a
         # later call (evaluate_model on a bigger batch, another trainer) needs more, which would leave a
         # captured hipGraph replaying into freed memory
@@ -476,13 +477,29 @@ class FusedTrainer:
             if not self._batches:
                 return 0.0
             if self._step_host is not None:
+                host = self._step_host_np
+                if self._poll:
+                    host.fill(np.nan)   # sentinel: every step loss is a finite number
                 if last == 0:   # one step per epoch: its loss goes from the gradient's tail slot to the host
                     self._step_host.copy_(tail, non_blocking=True)
                 else:
                     self._step_loss[last:last + 1].copy_(tail)
                     self._step_host.copy_(self._step_loss, non_blocking=True)
+                if self._poll:   # watch the pinned slots instead of sleeping in the stream sync (see _wait_for_losses)
+                    spins, deadline = 0, None
+                    while True:
+                        total = float(host.sum(dtype=np.float64))
+                        if total == total:
+                            return total
+                        spins += 1
+                        if spins & 0xFFF == 0:
+                            now = time()
+                            deadline = deadline or now + 5.0
+                            if now > deadline:
+                                torch.cuda.current_stream().synchronize()
+                                deadline = now + 1e9
                 torch.cuda.current_stream().synchronize()
-                return float(self._step_host.numpy().sum(dtype=np.float64))
+                return float(host.sum(dtype=np.float64))
             self._step_loss[last:last + 1].copy_(tail)
             return float(sum(self._step_loss.cpu().tolist()))
         # one device->host copy per epoch; the reference adds one float per optimizer step

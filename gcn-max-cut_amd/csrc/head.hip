@@ -102,16 +102,33 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         }
     }
     const float bias0 = a.b2[0], bias1 = a.b2[1], bias2 = a.b2[2];
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) {  // fold the slice-group partials, ascending
-        float z = 0.f;
-        for (int p0 = 0; p0 < a.zparts; p0 += 8) {
-            float t[8];
+    // fold the slice-group partials, ascending.  A thread owns up to kFoldElems elements (i, i + T, i + 2T);
+    // every load of a round - kFoldRound partials of ALL its elements - is requested before the first add:
+    // one memory round trip per round instead of one per (element, 8 partials).  A single n = 1000 graph has
+    // 32 partials (one workgroup per slice): 4 round trips where there were 12; the 160-graph batch (8
+    // partials) 1 where there were 3.  Same summation order as before: bitwise the same Z.
+    constexpr int kFoldElems = 3, kFoldRound = 8;
+    for (int i0 = threadIdx.x; i0 < 3 * n; i0 += kFoldElems * (int)blockDim.x) {
+        float z[kFoldElems] = {};
+        for (int p0 = 0; p0 < a.zparts; p0 += kFoldRound) {
+            float t[kFoldElems][kFoldRound];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = p0 + u < a.zparts ? a.Z0[((long)(p0 + u) * a.b.R + r0) * 3 + i] : 0.f;
+            for (int e = 0; e < kFoldElems; ++e) {
+                const int i = min(i0 + e * (int)blockDim.x, 3 * n - 1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) z += t[u];
+                for (int u = 0; u < kFoldRound; ++u)
+                    t[e][u] = p0 + u < a.zparts ? a.Z0[((long)(p0 + u) * a.b.R + r0) * 3 + i] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < kFoldElems; ++e)
+#pragma unroll
+                for (int u = 0; u < kFoldRound; ++u) z[e] += t[e][u];
         }
-        sA[i] = z;
+#pragma unroll
+        for (int e = 0; e < kFoldElems; ++e) {
+            const int i = i0 + e * (int)blockDim.x;
+            if (i < 3 * n) sA[i] = z[e];
+        }
     }
     if (threadIdx.x < 12) sA[3 * n + threadIdx.x] = 0.f;
     if (threadIdx.x < 4) sS[n + threadIdx.x] = 3;  // a class no node has
