@@ -26,8 +26,9 @@ The JSON line also carries
                   on the same 160 graphs, one hipGraph per epoch: the like-for-like partner of
   cpu_baseline  - the CPU oracle timed on this box's host cores on a bounded sample, rank 0, N=1 only:
                   variant A = oracle/ref_dense.py (reference-structured torch-CPU port: dense [n,1000]
-                  GEMM, per-row Python one-hot, dense loss, one Adam step per graph) at all threads
-                  (`value`) and at 1 thread; variant B = oracle/gcn_oracle.c (scalar C: CSR SpMM, fused
+                  GEMM, per-row Python one-hot, dense loss, one Adam step per graph) at torch's default
+                  thread count, at 16 and at 1 thread (`value` = the best of them, `cores` says which);
+                  variant B = oracle/gcn_oracle.c (scalar C: CSR SpMM, fused
                   argmax / loss), 1 thread.
 """
 from __future__ import annotations
@@ -414,15 +415,24 @@ def cpu_baseline(args, graphs, terms, net):
         return {"value": 1.0 / (per * EPOCH_GRAPHS), "cores": cores, "ms_per_graph_step": per * 1e3,
                 "sample": f"{k} sequential graph-steps (n={args.nodes} d={args.degree}, hidden {args.hidden}) of {what}, {t_total:.1f} s"}
 
-    a_all = rec(*run_a(all_threads), all_threads, "the reference-structured torch-CPU oracle (variant A)")
-    a_one = rec(*run_a(1), 1, "the reference-structured torch-CPU oracle (variant A)")
+    what_a = "the reference-structured torch-CPU oracle (variant A)"
+    a_all = rec(*run_a(all_threads), all_threads, what_a)
+    mid = min(16, all_threads)   # a GPU box hands one GPU's job a share of the host: many more threads than that oversubscribe
+    a_mid = rec(*run_a(mid), mid, what_a) if mid not in (1, all_threads) else None
+    a_one = rec(*run_a(1), 1, what_a)
     b_one = rec(*run_b(), 1, "the scalar C oracle: CSR SpMM, fused argmax/loss (variant B)")
+    variants = {"A_all_threads": a_all, "A_1_thread": a_one, "B_sparse_c_1_thread": b_one}
+    if a_mid is not None:
+        variants[f"A_{mid}_threads"] = a_mid
+    best = max((v for k, v in variants.items() if k.startswith("A_")), key=lambda v: v["value"])
     return {
-        "value": a_all["value"], "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)",
-        "cores": all_threads, "kind": "port", "sample": a_all["sample"],
+        # the reference-structured variant at the thread count that serves it best (all of them are listed)
+        "value": best["value"], "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)",
+        "cores": best["cores"], "kind": "port", "sample": best["sample"],
         "schedule": "one Adam step per graph (reference schedule; compare with `sequential`, not with `value`)",
-        "variants": {"A_all_threads": a_all, "A_1_thread": a_one, "B_sparse_c_1_thread": b_one},
-        "host_cpus": os.cpu_count(), "cpu_model": cpu_model_name(), "torch": torch.__version__,
+        "variants": variants,
+        "host_cpus": os.cpu_count(), "torch_default_threads": all_threads, "cpu_model": cpu_model_name(),
+        "torch": torch.__version__,
     }
 
 

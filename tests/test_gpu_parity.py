@@ -1007,7 +1007,7 @@ def test_bench_line_contract(pkg):
     assert "roofline_fused" not in d and "survey_unfused_GBps" not in json.dumps(d)
     q = d["sequential"]
     assert q["optimizer_steps_per_epoch"] == 8 and q["value"] > 0
-    assert set(c["variants"]) == {"A_all_threads", "A_1_thread", "B_sparse_c_1_thread"}
+    assert {"A_all_threads", "A_1_thread", "B_sparse_c_1_thread"} <= set(c["variants"])
     assert c["variants"]["A_1_thread"]["cores"] == 1 and c["cpu_model"] and c["gpu_sequential_over_cpu"] > 0
 
 
