@@ -130,8 +130,16 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     backend = None
-    if world > 1:
+    # GCN_MAXCUT_DP_SINGLE_RANK=1 (one-GPU boxes): ONE rank over RCCL runs the data-parallel step sequence -
+    # communicator set-up, the collective on the launch stream and graph capture beside RCCL's threads
+    single_dp = world == 1 and os.environ.get("GCN_MAXCUT_DP_SINGLE_RANK") == "1"
+    dp = world > 1 or single_dp
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if single_dp:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
@@ -167,7 +175,7 @@ def main():
     spmm_bytes = trainer._batches[0].spmm_bytes(args.hidden)
 
     def sync():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -182,7 +190,7 @@ def main():
             loss = tr.epoch(data)
         sync()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if dp:
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()), loss
 
@@ -193,7 +201,7 @@ def main():
 
     # N > 1, weak run: the same job on the strong split (160 graphs in total, 160 / N per rank)
     strong = None
-    if world > 1 and args.scaling == "weak" and args.mode == "batched":
+    if dp and args.scaling == "weak" and args.mode == "batched":
         per = min(len(dataset), max(1, EPOCH_GRAPHS // world))
         sub = {k: dataset[k] for k in list(dataset)[:per]}
         tr_s = T.FusedTrainer(net, opt, cfg, graphs_per_step=per, local_shard=True)
@@ -203,7 +211,7 @@ def main():
 
     # per-step collective time (events on the launch stream around the eager all-reduce), N > 1
     allreduce_ms = None
-    if world > 1:
+    if dp:
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
         sync()
         for a, b in evs:
@@ -252,7 +260,7 @@ def main():
     # the reference's own schedule on the same graphs: one Adam step per graph (TrainingNeural.py:371-386),
     # one hipGraph per epoch - what `cpu_baseline` (same schedule, host cores) is to be compared with
     sequential = None
-    if world == 1 and args.mode == "batched" and not args.no_sequential:
+    if not dp and args.mode == "batched" and not args.no_sequential:
         torch.manual_seed(0)
         net_s, embed_s, opt_s = T.setup_model_and_optimizer(cfg)
         net_s.train()
@@ -265,7 +273,7 @@ def main():
                       "schedule": "one Adam step per graph, dataset order (reference schedule), hipGraph per epoch"}
 
     if rank != 0:
-        if world > 1:
+        if dp:
             dist.destroy_process_group()
         return
 
@@ -285,7 +293,7 @@ def main():
             "graphs_per_gpu": gpg, "rows_per_gpu": gpg * n, "nnz_per_gpu": gpg * n * d,
             "hidden_dim": args.hidden, "mode": args.mode, "epoch_graphs": EPOCH_GRAPHS,
             "optimizer_steps_per_step": len(trainer._batches),
-            "parallelism": f"dp{world}" if world > 1 else "single",
+            "parallelism": f"dp{world}" if dp else "single",
         },
         "backend": backend,
         "last_loss": last_loss,
@@ -349,13 +357,13 @@ def main():
     else:
         out["roofline"] = None
 
-    if world == 1 and not args.no_cpu_baseline:
+    if not dp and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, graphs, terms, net)
         if sequential is not None:   # same schedule on both sides: GPU reference-schedule rate / CPU rate
             out["cpu_baseline"]["gpu_sequential_over_cpu"] = sequential["value"] / out["cpu_baseline"]["value"]
         out["parity"] = parity_gate(pkg, T, net, dataset)
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

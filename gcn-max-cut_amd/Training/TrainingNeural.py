@@ -32,7 +32,7 @@ import torch.nn.functional as F  # noqa: F401
 
 from .. import hip
 from ..commons import open_file, save_object  # noqa: F401
-from ..engine import PARAM_ORDER, FusedEngine, shard_for_rank
+from ..engine import PARAM_ORDER, FusedEngine, dp_active, shard_for_rank
 from ..graph import GraphBatch, GraphHandle
 
 TORCH_DEVICE = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -330,7 +330,10 @@ class FusedTrainer:
         self.local_shard = local_shard
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
-        if self.world > 1 and hasattr(self.eng, "sync_replicas"):
+        # dp: steps run the data-parallel sequence (shard step -> all-reduce -> Adam).  More than one rank, or a
+        # single rank asked to (GCN_MAXCUT_DP_SINGLE_RANK=1: RCCL and the graphs around it on a one-GPU box)
+        self.dp = dp_active()
+        if self.dp and hasattr(self.eng, "sync_replicas"):
             self.eng.sync_replicas(0)   # one model: rank 0's parameters / moments on every replica
         self._plan_key = None
         self._ws: Optional[torch.Tensor] = None   # scratch of this trainer's steps (captured graphs point into it)
@@ -428,7 +431,7 @@ class FusedTrainer:
                     eng.grad[:eng.count + 1].zero_()
                 else:
                     eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]), ws=self._ws)
-                if self.world > 1:
+                if self.dp:
                     eng.allreduce_grad()
                 self._step_loss[i:i + 1].copy_(tail)
                 eng.adam_step(lr, betas, eps)
@@ -440,7 +443,7 @@ class FusedTrainer:
             self._loss_host_np.fill(np.nan)   # sentinel: every loss is a finite number (<= 0)
         if use_graph:
             self._replay_epoch()
-        elif self.world == 1 and hasattr(eng, "train_step"):
+        elif not self.dp and hasattr(eng, "train_step"):
             eng.sync_step_dev()
             self._enqueue_epoch()
         else:
@@ -463,7 +466,7 @@ class FusedTrainer:
                 else:
                     eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]),
                                       **({"ws": self._ws} if self._ws is not None else {}))
-                if self.world > 1:
+                if self.dp:
                     eng.allreduce_grad()               # ONE RCCL all-reduce of [gradient | loss] per step, eager
                     if i != last:                      # the last step's slot is read in place below
                         self._step_loss[i:i + 1].copy_(tail)
@@ -473,7 +476,7 @@ class FusedTrainer:
                     eng._dev_step += 1
                 else:
                     eng.adam_step(lr, betas, eps)
-        if self.world > 1:   # one host sync per epoch
+        if self.dp:   # one host sync per epoch
             if not self._batches:
                 return 0.0
             if self._step_host is not None:
@@ -555,13 +558,13 @@ class FusedTrainer:
         epoch, which removes the per-launch host cost."""
         if self._graph_env is None:   # process-wide facts, looked up once
             self._graph_env = torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0"
-        return (self.allow_graph and self.world == 1 and self._graph_env and len(self._batches) >= 1
+        return (self.allow_graph and not self.dp and self._graph_env and len(self._batches) >= 1
                 and hasattr(self.eng, "train_step"))
 
     def _use_dp_graph(self) -> bool:
         """Data-parallel ranks: the launches on either side of the (eager) all-reduce are replayed from
         hipGraphs - one per step for forward/loss/backward, one for Adam."""
-        return (self.allow_graph and self.world > 1 and hasattr(self.eng, "adam_step_dev") and self._ws is not None
+        return (self.allow_graph and self.dp and hasattr(self.eng, "adam_step_dev") and self._ws is not None
                 and torch.cuda.is_available() and os.environ.get("GCN_MAXCUT_HIPGRAPH", "1") != "0")
 
     def _dp_graphs(self):

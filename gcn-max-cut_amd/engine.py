@@ -8,6 +8,7 @@ All kernels are enqueued on torch's current HIP stream through ``gcnmaxcut.h``.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -209,7 +210,7 @@ class FusedEngine:
         """Data-parallel start-up: every rank takes rank ``src``'s parameters, Adam moments and step
         count, so that replicas built from different RNG states apply the all-reduced gradient to the
         SAME weights (the reference has one model; N replicas must be that one model)."""
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        if not dp_active():
             return
         for buf in (self.flat, self.m, self.v):
             dist.broadcast(buf, src)
@@ -223,9 +224,18 @@ class FusedEngine:
         """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""
         if local_loss_sum is not None:
             self.grad[self.count] = local_loss_sum
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dp_active():
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM)
         return self.grad[self.count] if local_loss_sum is not None else None
+
+
+def dp_active() -> bool:
+    """Do steps run the data-parallel sequence (shard step -> all-reduce -> Adam)?  Yes with more than one
+    rank; also with ONE rank when GCN_MAXCUT_DP_SINGLE_RANK=1 - a one-GPU box then exercises RCCL itself
+    (communicator set-up, the collective on the launch stream, hipGraph capture beside its watchdog)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("GCN_MAXCUT_DP_SINGLE_RANK") == "1"
 
 
 def shard_for_rank(n_items: int, rank: int, world: int) -> range:

@@ -1030,3 +1030,29 @@ def test_bench_two_rank_rehearsal_on_one_gpu(pkg):
     assert d["strong_scaling"]["graphs_per_gpu"] == 6 and d["strong_scaling"]["value"] > 0
     assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
     assert "cpu_baseline" not in d
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_rank_over_rccl(pkg):
+    """RCCL itself on the one GPU a test box has: GCN_MAXCUT_DP_SINGLE_RANK=1 makes a world of ONE rank run the
+    data-parallel step sequence over backend "nccl" - communicator set-up, replica broadcast, the [gradient | loss]
+    all-reduce on the launch stream between replayed hipGraphs (captured while RCCL's watchdog thread is alive).
+    The loss must be the one the single-GPU fused step reaches after the same number of steps."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        base.pop(k, None)
+    args = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
+            "--graphs-per-gpu", "6", "--no-cpu-baseline", "--no-sequential", "--no-probe"]
+    lines = {}
+    for tag, env in (("rccl", dict(base, GCN_MAXCUT_DP_SINGLE_RANK="1")), ("single", base)):
+        out = subprocess.run(args, capture_output=True, text=True, timeout=400, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        (line,) = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+        lines[tag] = json.loads(line)
+    d, s = lines["rccl"], lines["single"]
+    assert d["backend"] == "nccl" and d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"
+    assert d["launch"] == "hipGraphs around the eager all-reduce" and s["launch"] == "hipGraph replay"
+    assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
+    assert d["last_loss"] == s["last_loss"]          # same six graphs, same six steps, integer-valued loss
