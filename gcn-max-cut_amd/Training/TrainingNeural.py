@@ -335,6 +335,8 @@ class FusedTrainer:
         self.dp = dp_active()
         if self.dp and hasattr(self.eng, "sync_replicas"):
             self.eng.sync_replicas(0)   # one model: rank 0's parameters / moments on every replica
+        # the fused forward of this trainer's steps reads the engine's slab copy of conv1.weight (FusedEngine.ensure_slab)
+        self._slab = {"slab": True} if hasattr(self.eng, "ensure_slab") else {}
         self._plan_key = None
         self._ws: Optional[torch.Tensor] = None   # scratch of this trainer's steps (captured graphs point into it)
         self._graph_key = None
@@ -455,6 +457,8 @@ class FusedTrainer:
             graphs = self._dp_graphs() if self._use_dp_graph() else None
             if graphs is not None:
                 eng.sync_step_dev()
+                if self._slab:
+                    eng.ensure_slab()   # (a launch only when torch wrote the parameters since the last step)
             for i, batch in enumerate(self._batches):
                 if batch.B == 0:
                     # this rank's shard of the step is empty (last group smaller than the world): it
@@ -465,7 +469,7 @@ class FusedTrainer:
                     graphs[0][i].replay()              # forward + loss + backward + gradient fold of my shard
                 else:
                     eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]),
-                                      **({"ws": self._ws} if self._ws is not None else {}))
+                                      **({"ws": self._ws} if self._ws is not None else {}), **self._slab)
                 if self.dp:
                     eng.allreduce_grad()               # ONE RCCL all-reduce of [gradient | loss] per step, eager
                     if i != last:                      # the last step's slot is read in place below
@@ -580,17 +584,17 @@ class FusedTrainer:
                 fb.append(None)
                 continue
             out = (self._out[0], self._out[1], self._loss_slots[i])
-            eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws)     # eager once: warms the kernels
+            eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws, **self._slab)     # eager once: warms the kernels
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws)
+                eng.train_fwd_bwd(batch, cfg.C, out=out, ws=self._ws, **self._slab)
             fb.append(g)
         before, flat, m, v = eng.step_count, eng.flat.clone(), eng.m.clone(), eng.v.clone()
         eng.sync_step_dev()
-        eng.adam_step_dev(lr, betas, eps)                              # eager once (state restored below)
+        eng.adam_step_dev(lr, betas, eps, **self._slab)                # eager once (state restored below)
         ga = torch.cuda.CUDAGraph()
         with torch.cuda.graph(ga):
-            eng.adam_step_dev(lr, betas, eps)
+            eng.adam_step_dev(lr, betas, eps, **self._slab)
         eng.flat.copy_(flat); eng.m.copy_(m); eng.v.copy_(v)
         eng.step_count = before
         eng._dev_step = -1                                             # (the capture pass counted on the host only)
@@ -603,7 +607,7 @@ class FusedTrainer:
         lr, betas, eps = self._hyper()
         for i, batch in enumerate(self._batches):
             eng.train_step(batch, lr, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]), betas=betas, eps=eps,
-                           ws=self._ws)
+                           ws=self._ws, **self._slab)
         if with_readback and self._loss_host is not None:
             self._loss_host.copy_(self._loss_slots, non_blocking=True)
 
@@ -625,6 +629,8 @@ class FusedTrainer:
             self._graph, self._graph_steps = graph, len(self._batches)
             self._loss_host.copy_(self._loss_slots, non_blocking=True)   # this (eager) epoch's losses
             return
+        if self._slab:
+            eng.ensure_slab()   # (a launch only when torch wrote the parameters since the last replay)
         self._graph.replay()
         eng.step_count += self._graph_steps
         eng._dev_step += self._graph_steps

@@ -54,6 +54,8 @@ struct AdamDevArgs {
     double lr, beta1, beta2;
     float eps;
     const int *step_counter;
+    float *w1_slab;  // optional: slab copy of the first N*F parameters (conv1.weight), refreshed with the update
+    int N, F;
 };
 
 __global__ __launch_bounds__(256) void adam_devstep_kernel(AdamDevArgs d) {
@@ -79,6 +81,10 @@ __global__ __launch_bounds__(256) void adam_devstep_kernel(AdamDevArgs d) {
         reinterpret_cast<float4 *>(a.p)[i] = p;
         reinterpret_cast<float4 *>(a.m)[i] = m;
         reinterpret_cast<float4 *>(a.v)[i] = v;
+        if (d.w1_slab && i * 4 < (long)d.N * d.F) {  // (F % 4 == 0: a float4 never leaves its slab row)
+            const long e = i * 4, r = e / d.F;
+            *reinterpret_cast<float4 *>(d.w1_slab + gmc::slab16_index(r, (int)(e - r * d.F), d.N)) = p;
+        }
     }
     if (blockIdx.x == 0) {
         const long i = (n4 << 2) + threadIdx.x;
@@ -90,16 +96,16 @@ __global__ void adam_tick_kernel(int *step_counter) { *step_counter += 1; }
 
 }  // namespace
 
-extern "C" int gmc_adam_devstep_f32(float *param, const float *grad, float *m, float *v, int64_t count,
-                                    double lr, double beta1, double beta2, double eps, int32_t *step_counter,
-                                    gmc_stream_t stream) {
+namespace {
+int adam_devstep(float *param, const float *grad, float *m, float *v, int64_t count, double lr, double beta1,
+                 double beta2, double eps, int32_t *step_counter, gmc_stream_t stream, float *w1_slab, int N, int F) {
     if (!param || !grad || !m || !v || !step_counter) return GMC_ERR_NULL;
     if (count < 0) return GMC_ERR_SHAPE;
     if (!gmc_aligned16(param) || !gmc_aligned16(grad) || !gmc_aligned16(m) || !gmc_aligned16(v))
         return GMC_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (count > 0) {
-        AdamDevArgs d{param, grad, m, v, (long)count, lr, beta1, beta2, (float)eps, step_counter};
+        AdamDevArgs d{param, grad, m, v, (long)count, lr, beta1, beta2, (float)eps, step_counter, w1_slab, N, F};
         long blocks = ((count >> 2) + 255) / 256;
         if (blocks < 1) blocks = 1;
         if (blocks > 2048) blocks = 2048;
@@ -110,6 +116,24 @@ extern "C" int gmc_adam_devstep_f32(float *param, const float *grad, float *m, f
     hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
     GMC_LAUNCH_CHECK();
     return GMC_OK;
+}
+}  // namespace
+
+extern "C" int gmc_adam_devstep_f32(float *param, const float *grad, float *m, float *v, int64_t count,
+                                    double lr, double beta1, double beta2, double eps, int32_t *step_counter,
+                                    gmc_stream_t stream) {
+    return adam_devstep(param, grad, m, v, count, lr, beta1, beta2, eps, step_counter, stream, nullptr, 0, 0);
+}
+
+// gmc_adam_devstep_f32 over the flat [W1 | b1 | W2 | b2] buffer of an N x F x 3 model that also refreshes the
+// slab copy of W1 (gmc_model.W1_slab; NULL = none) with the updated values
+extern "C" int gmc_adam_devstep_model_f32(float *param, const float *grad, float *m, float *v, int32_t N, int32_t F,
+                                          float *w1_slab, double lr, double beta1, double beta2, double eps,
+                                          int32_t *step_counter, gmc_stream_t stream) {
+    if (N <= 0 || F <= 0 || F % 4) return GMC_ERR_SHAPE;
+    if (w1_slab && !gmc_aligned16(w1_slab)) return GMC_ERR_ALIGN;
+    const int64_t count = (int64_t)N * F + F + (int64_t)F * 3 + 3;
+    return adam_devstep(param, grad, m, v, count, lr, beta1, beta2, eps, step_counter, stream, w1_slab, N, F);
 }
 
 extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count,

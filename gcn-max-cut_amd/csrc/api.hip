@@ -17,10 +17,10 @@ bool gmc_bwd1_fits(const gmc_batch *b);
 int gmc_head_launch(const gmc_batch *, const float *, int32_t, const float *, float, float *, int32_t *, float *,
                     float *, float *, int *, hipStream_t);
 int gmc_finish_launch(const float *, const float *, const float *, int, int, int, int, int, float *, float *, float *,
-                      float *, double, double, double, double, int *, const float *, hipStream_t);
+                      float *, double, double, double, double, int *, const float *, hipStream_t, float *);
 int gmc_loss_tail_launch(const float *, int, float *, hipStream_t);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
-                        hipStream_t);
+                        hipStream_t, const float *, int);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
                         int, hipStream_t);
 int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
@@ -115,6 +115,7 @@ int check(const gmc_batch *b, const gmc_model *m) {
     if (b->B < 0 || b->R < 0 || b->nnz < 0 || m->N <= 0 || m->F <= 0) return GMC_ERR_SHAPE;
     if (m->F % 4 || m->F > 1024) return GMC_ERR_UNSUPPORTED;  // float4 rows, <= 4 passes per lane
     if (!(m->dropout_p >= 0.f && m->dropout_p < 1.f)) return GMC_ERR_SHAPE;
+    if (m->W1_slab && !gmc_aligned16(m->W1_slab)) return GMC_ERR_ALIGN;
     if (b->B > 0 && (b->n_max < 3 || b->n_max > GMC_MAX_GRAPH_NODES)) return GMC_ERR_GRAPH_SIZE;
     if (b->n_max > m->N) return GMC_ERR_SHAPE;  // more nodes than rows of conv1.weight
     return GMC_OK;
@@ -136,7 +137,7 @@ int aggregate(const gmc_batch *b, const Workspace &w, const float *X, float *Y, 
 int forward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, hipStream_t st) {
     const int F = m->F;
     if (w.fs && fuse_enabled() && !dropout_on(m))  // T0 lives only in LDS
-        return gmc_fwd1_lds_launch(b, m->W1, m->b1, m->W2, w.H, w.Z0, F, st);
+        return gmc_fwd1_lds_launch(b, m->W1, m->b1, m->W2, w.H, w.Z0, F, st, m->W1_slab, m->N);
     // layer 1 feature transform as a row gather of W1:  T0 = dinv o (A_val @ W1[:n])
     int rc = w.fs ? gmc_spmm_lds_launch(b, m->W1, F, 0, 1, 1, b->dinv, nullptr, 0, w.T0, w.ld, 1, F, nullptr,
                                         nullptr, GMC_K_GATHER_W1, st)
@@ -158,6 +159,7 @@ struct AdamFuse {  // optional Adam fused into the gradient fold (single GPU)
     float *param = nullptr, *m = nullptr, *v = nullptr;
     double lr = 0, beta1 = 0, beta2 = 0, eps = 0;
     int *step_counter = nullptr;
+    float *w1_slab = nullptr;  // slab copy of W1 to refresh with the update (gmc_model.W1_slab)
 };
 
 // loss_tail: per-graph losses whose sum goes to the slot after the gradient (GMC_MODEL_GRAD_TAIL), or nullptr
@@ -180,7 +182,7 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
         return gmc_finish_launch(w.dw1part, w.part, w.db2part, chunks, b->n_max, m->N, m->F, b->B, grad,
                                  af ? af->param : nullptr, af ? af->m : nullptr, af ? af->v : nullptr,
                                  af ? af->lr : 0, af ? af->beta1 : 0, af ? af->beta2 : 0, af ? af->eps : 0,
-                                 af ? af->step_counter : nullptr, loss_tail, st);
+                                 af ? af->step_counter : nullptr, loss_tail, st, af ? af->w1_slab : nullptr);
     }
     if (af) return GMC_ERR_UNSUPPORTED;  // the fused Adam rides on the fused backward
     int rc = w.fs ? gmc_hidden_bwd_slab_launch(w.H, w.GY2, W2b, b->dinv, Gs, w.part, b->R, m->F, w.fs, st)
@@ -321,17 +323,17 @@ extern "C" int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model,
     return backward_body(batch, model, w, grad, st, nullptr, tail ? loss : nullptr);
 }
 
-int gmc_adam_devstep_f32(float *, const float *, float *, float *, int64_t, double, double, double, double, int32_t *,
-                         gmc_stream_t);
+extern "C" int gmc_adam_devstep_model_f32(float *, const float *, float *, float *, int32_t, int32_t, float *, double,
+                                          double, double, double, int32_t *, gmc_stream_t);
 
 extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, float *param, float C,
                                   void *workspace, size_t workspace_bytes, float *P, int32_t *S, float *loss,
                                   float *grad, float *mom, float *var, double lr, double beta1, double beta2,
-                                  double eps, int32_t *step_counter, gmc_stream_t stream) {
+                                  double eps, int32_t *step_counter, float *w1_slab, gmc_stream_t stream) {
     if (!param || !grad || !mom || !var || !step_counter) return GMC_ERR_NULL;
     if (!gmc_aligned16(param) || !gmc_aligned16(mom) || !gmc_aligned16(var)) return GMC_ERR_ALIGN;
     const long nW1 = (long)N * F;
-    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3, 0.f, 0u, 0u};
+    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3, 0.f, 0u, 0u, w1_slab};
     int rc = check(batch, &model);
     if (rc) return rc;
     if (!P || !workspace) return GMC_ERR_NULL;
@@ -339,12 +341,11 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     Workspace w = carve(batch, &model, 1, workspace);
     if (w.bytes > workspace_bytes) return GMC_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t count = nW1 + F + (int64_t)F * 3 + 3;
     const bool fused = batch->R > 0 && w.fs && fuse_enabled() && gmc_bwd1_fits(batch);
     if (!fused) {  // general shapes: gradient, then the stand-alone Adam
         rc = gmc_train_fwd_bwd(batch, &model, C, workspace, workspace_bytes, P, S, loss, grad, stream);
         if (rc) return rc;
-        return gmc_adam_devstep_f32(param, grad, mom, var, count, lr, beta1, beta2, eps, step_counter, stream);
+        return gmc_adam_devstep_model_f32(param, grad, mom, var, N, F, w1_slab, lr, beta1, beta2, eps, step_counter, stream);
     }
     rc = forward_body(batch, &model, w, st);
     if (rc) return rc;
@@ -354,6 +355,7 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     AdamFuse af;
     af.param = param; af.m = mom; af.v = var; af.lr = lr; af.beta1 = beta1; af.beta2 = beta2; af.eps = eps;
     af.step_counter = step_counter;
+    af.w1_slab = w1_slab;
     return backward_body(batch, &model, w, grad, st, &af);
 }
 

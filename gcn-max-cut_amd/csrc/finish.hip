@@ -24,6 +24,7 @@ struct FinishArgs {
     float eps;
     const int *step_counter;  // device; already advanced by this step's head launch: the update uses it as is
     const float *loss;        // [B] per-graph losses, or nullptr: their sum goes to grad[count] (GMC_MODEL_GRAD_TAIL)
+    float *w1_slab;           // optional slab copy of W1 (gmc_model.W1_slab): receives the updated W1 as well
 };
 
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, float w1, float b2, float w2,
@@ -77,6 +78,10 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
             reinterpret_cast<float4 *>(a.param)[i] = p;
             reinterpret_cast<float4 *>(a.m)[i] = m;
             reinterpret_cast<float4 *>(a.v)[i] = v;
+            if (a.w1_slab) {  // F % 4 == 0: the four columns stay inside one 16-column slab row
+                const long e = i * 4, r = e / a.F;
+                *reinterpret_cast<float4 *>(a.w1_slab + gmc::slab16_index(r, (int)(e - r * a.F), a.N)) = p;
+            }
         }
     }
     // tail of the flat buffer: b1 [F], W2 [F,3] (column partials of the chunks, ascending order)
@@ -143,9 +148,10 @@ int gmc_loss_tail_launch(const float *loss, int B, float *slot, hipStream_t st) 
 // param == nullptr -> gradients only.  *step_counter (device) must already hold this step's number.
 int gmc_finish_launch(const float *dw1part, const float *colpart, const float *db2part, int chunks, int n_max,
                       int N, int F, int B, float *grad, float *param, float *m, float *v, double lr, double beta1,
-                      double beta2, double eps, int *step_counter, const float *loss_for_tail, hipStream_t st) {
+                      double beta2, double eps, int *step_counter, const float *loss_for_tail, hipStream_t st,
+                      float *w1_slab) {
     FinishArgs a{dw1part, colpart, db2part, chunks, n_max, N, F, B, grad, param, m, v, lr, beta1, beta2, (float)eps,
-                 step_counter, loss_for_tail};
+                 step_counter, loss_for_tail, param ? w1_slab : nullptr};
     const long n4 = (long)N * F / 4;
     long blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -64,8 +64,13 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
         // W1 tile of slice s, row-major [N][ldx].  Pad columns (>= F, last slice only) load the last
         // valid column group again: finite values, so that the masked scale below makes exact zeros
+        // Source: the slab copy of W1 when the caller keeps one (a wave's 16 rows x 64 B are then ONE contiguous
+        // KiB instead of 16 pieces at a 4F-byte stride: -8 % kernel time), else the row-major table
         auto dma = [&](int s) {
-            dma_tile<FS, ACC>(a.X + min(s * FS + 4 * q, a.F - 4), a.x_rs, n, true, lrow, bufA);
+            const int col = s * FS + 4 * q;
+            const int cs = min(col, ((a.F + 15) & ~15) - 4);
+            const long off = a.x_slab16 ? gmc::slab16_index(0, cs, a.x_rows) : (long)min(col, a.F - 4);
+            dma_tile<FS, ACC>(a.X + off, a.x_rs, n, true, lrow, bufA);
         };
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
@@ -233,8 +238,9 @@ int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
 
 // fused layer-1 forward: H (slab layout) = relu(dinv o (A @ (dinv o (A_val @ W1[:n]))) + b1) and
 // Zpart[group][r][:] = dinv[r] * (H[r, group's columns] @ W2[group's rows])
+// W1_slab (optional): the [ceil(F/16)][N][16] copy of W1 (gmc_w1_slab_f32); N = rows of W1
 int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, const float *W2, float *H,
-                        float *Zpart, int F, hipStream_t st) {
+                        float *Zpart, int F, hipStream_t st, const float *W1_slab, int N) {
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
@@ -245,7 +251,8 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
     const int total = b->B * groups, cus = device_cus();
     const int ipw = (total + cus - 1) / cus, grid = (total + ipw - 1) / ipw;
     TileArgs a{*b, W1, (long)F, (long)fs, 1, b->ell_vals != nullptr, b->dinv, b1, 1, H, (long)fs, (long)b->R * fs,
-               F, slices, groups, W2, Zpart, ipw};
+               F, slices, groups, W2, Zpart, ipw, 0, 0};
+    if (W1_slab) { a.X = W1_slab; a.x_rs = 16; a.x_slab16 = 1; a.x_rows = N; }
     const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     GmcProbeScope probe(GMC_K_FWD1_FUSED, st);
     if (b->ell_width == 8) {

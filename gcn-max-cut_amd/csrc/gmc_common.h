@@ -73,4 +73,10 @@ __device__ __forceinline__ void f4_fma(float4 &a, float s, const float4 &b) {
     a.x = fmaf(s, b.x, a.x); a.y = fmaf(s, b.y, a.y); a.z = fmaf(s, b.z, a.z); a.w = fmaf(s, b.w, a.w);
 }
 
+// W1 slab copy (gmc_model.W1_slab): element (row, col) of the [N,F] table lives at ((col/16)*N + row)*16 + col%16,
+// i.e. [ceil(F/16)][N][16] - the 64 B a tile row of a 16-column slice needs are contiguous with the next row's.
+__host__ __device__ __forceinline__ long slab16_index(long row, int col, int N) {
+    return ((long)(col >> 4) * N + row) * 16 + (col & 15);
+}
+
 }  // namespace gmc

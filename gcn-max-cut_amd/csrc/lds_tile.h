@@ -77,6 +77,8 @@ struct TileArgs {
     const float *W2;     // optional fused (Y o scale) @ W2
     float *Zpart;        // [groups][R][3]
     int items_per_wg;    // fwd1: (graph, group) items per persistent workgroup
+    int x_slab16;        // fwd1: X is the 16-column slab copy of the shared table (gmc::slab16_index) with
+    int x_rows;          //       x_rows rows; 0 = row-major X (x_rs)
 };
 
 // block -> (graph, group): all groups of a graph on one XCD (blocks are dealt round-robin

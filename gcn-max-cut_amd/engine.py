@@ -52,6 +52,12 @@ class FusedEngine:
         self._ws: Optional[torch.Tensor] = None
         self._model = hip.GmcModel()
         self._refresh_model()
+        # slab copy of conv1.weight for the fused forward (gmc_model.W1_slab): used by the calls that ask for it
+        # (FusedTrainer's steps), kept current by the fused Adam kernels, re-built when torch wrote the parameters
+        self.w1_slab: Optional[torch.Tensor] = None
+        self._slab_sig = None
+        self._adopted: List = []
+        self.slab_enabled = hip.HAS_SLAB and os.environ.get("GCN_MAXCUT_W1_SLAB", "1") != "0"
 
     # ---- parameters
     def views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -65,6 +71,37 @@ class FusedEngine:
         self._model = hip.GmcModel(N=self.N, F=self.F, K=self.K, flags=hip.MODEL_GRAD_TAIL,
                                    W1=hip.ptr(v["conv1.weight"]), b1=hip.ptr(v["conv1.bias"]),
                                    W2=hip.ptr(v["conv2.weight"]), b2=hip.ptr(v["conv2.bias"]))
+
+    # ---- slab copy of W1
+    def _param_signature(self):
+        # every torch-visible in-place write bumps the version counter of the tensor it went through: the flat
+        # buffer (and its views) or an adopted nn.Parameter.  The library's kernels write through raw pointers
+        # and bump nothing - they keep the slab current themselves.
+        return (self.flat._version,) + tuple(p._version for p in self._adopted)
+
+    def ensure_slab(self) -> int:
+        """Device pointer of the slab copy of conv1.weight (gmc_model.W1_slab), re-built first when a torch
+        operation wrote the parameters since it was last known to be current (optimizer.step(), load_state_dict,
+        a broadcast, ...).  0 when the copy is switched off (GCN_MAXCUT_W1_SLAB=0 / an older library).  A write
+        torch cannot see (``param.data`` arithmetic, foreign kernels) is picked up one step late: the Adam
+        kernels refresh the copy from the row-major weights on every step."""
+        if not self.slab_enabled:
+            return 0
+        sig = self._param_signature()
+        if self.w1_slab is None:
+            self.w1_slab = torch.empty(int(self.lib.gmc_w1_slab_floats(self.N, self.F)), dtype=torch.float32,
+                                       device=self.device)
+            self._slab_sig = None
+        if sig != self._slab_sig:
+            rc = self.lib.gmc_w1_slab_f32(hip.ptr(self.flat), self.N, self.F, hip.ptr(self.w1_slab), hip.stream())
+            hip.check(rc, "gmc_w1_slab_f32")
+            self._slab_sig = sig
+        return hip.ptr(self.w1_slab)
+
+    def _model_ref(self, slab: bool):
+        """byref(gmc_model) for a call; ``slab``: with the (current) slab copy of W1."""
+        self._model.W1_slab = self.ensure_slab() if slab else None
+        return C.byref(self._model)
 
     def set_dropout(self, p: float, seed: Optional[int] = None) -> None:
         """F.dropout between the layers (TrainingNeural.py:82) for the next forward / training calls:
@@ -92,6 +129,8 @@ class FusedEngine:
             if p.data_ptr() != views[k].data_ptr() or p.device != self.device:
                 views[k].copy_(p.detach().to(self.device, torch.float32))
                 p.data = views[k]
+        self._adopted = [named[k] for k in PARAM_ORDER]
+        self._slab_sig = None
 
     def owns(self, module: torch.nn.Module) -> bool:
         named = dict(module.named_parameters())
@@ -127,7 +166,8 @@ class FusedEngine:
         hip.check(rc, "gmc_forward")
         return P, S, loss
 
-    def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None, ws: Optional[torch.Tensor] = None):
+    def train_fwd_bwd(self, batch: GraphBatch, C_: float = 1.0, out=None, ws: Optional[torch.Tensor] = None,
+                      slab: bool = False):
         """forward + loss + backward for the batch's summed loss; gradient lands in
         ``self.grad[:count]`` - TrainingNeural.py:373-385.  ``ws``: caller-owned scratch (a trainer
         whose launches are captured into a hipGraph must own it: the engine's own scratch moves
@@ -142,14 +182,15 @@ class FusedEngine:
             self.grad[:self.count + 1].zero_()
             return P, S, loss
         ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, True)
-        rc = self.lib.gmc_train_fwd_bwd(batch.ref(), C.byref(self._model), C_, hip.ptr(ws), nbytes,
+        rc = self.lib.gmc_train_fwd_bwd(batch.ref(), self._model_ref(slab), C_, hip.ptr(ws), nbytes,
                                         hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad),
                                         hip.stream())
+        self._model.W1_slab = None
         hip.check(rc, "gmc_train_fwd_bwd")
         return P, S, loss
 
     def train_step(self, batch: GraphBatch, lr: float, C_: float = 1.0, out=None, betas=(0.9, 0.999),
-                   eps: float = 1e-8, ws: Optional[torch.Tensor] = None):
+                   eps: float = 1e-8, ws: Optional[torch.Tensor] = None, slab: bool = False):
         """One whole optimizer step (forward, loss, backward, fused gradient fold + Adam) - the
         single-GPU form of the loop body of train_single_epoch (TrainingNeural.py:373-386).
         Replay-invariant: the step number is read from / advanced in device memory."""
@@ -160,10 +201,13 @@ class FusedEngine:
             loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
         else:
             P, S, loss = out
+        tail = (self.ensure_slab() if slab else None, hip.stream()) if hip.HAS_SLAB else (hip.stream(),)
         rc = self.lib.gmc_train_step_f32(batch.ref(), self.N, self.F, hip.ptr(self.flat), C_, hip.ptr(ws), nbytes,
                                          hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad), hip.ptr(self.m),
                                          hip.ptr(self.v), lr, betas[0], betas[1], eps, hip.ptr(self.step_dev),
-                                         hip.stream())
+                                         *tail)
+        if not slab:
+            self._slab_sig = None   # W1 moved, the copy did not
         hip.check(rc, "gmc_train_step_f32")
         self.step_count += 1
         self._dev_step += 1
@@ -187,14 +231,22 @@ class FusedEngine:
                                    hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
                                    self.step_count, hip.stream())
         hip.check(rc, "gmc_adam_f32")
+        self._slab_sig = None   # W1 moved, the slab copy did not
 
-    def adam_step_dev(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8) -> None:
+    def adam_step_dev(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, slab: bool = False) -> None:
         """Same update with the step number read from (and advanced in) device memory, so the
         launch can be captured into a hipGraph and replayed (``step_dev`` must equal
-        ``step_count`` on entry; both advance by one)."""
-        rc = self.lib.gmc_adam_devstep_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
-                                           hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
-                                           hip.ptr(self.step_dev), hip.stream())
+        ``step_count`` on entry; both advance by one).  ``slab``: the updated conv1.weight goes to the slab
+        copy as well (which must be current: :meth:`ensure_slab`)."""
+        if slab and self.slab_enabled:
+            rc = self.lib.gmc_adam_devstep_model_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
+                                                     hip.ptr(self.v), self.N, self.F, self.ensure_slab(), lr, betas[0],
+                                                     betas[1], eps, hip.ptr(self.step_dev), hip.stream())
+        else:
+            rc = self.lib.gmc_adam_devstep_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
+                                               hip.ptr(self.v), self.count, lr, betas[0], betas[1], eps,
+                                               hip.ptr(self.step_dev), hip.stream())
+            self._slab_sig = None
         hip.check(rc, "gmc_adam_devstep_f32")
         self.step_count += 1
         self._dev_step += 1
@@ -218,6 +270,7 @@ class FusedEngine:
         dist.broadcast(step, src)
         self.step_count = int(step.item())
         self._dev_step = -1
+        self._slab_sig = None   # (a collective writes through raw pointers: no version counter moves)
         self.sync_step_dev()
 
     def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:

@@ -20,6 +20,7 @@ SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
     "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_ell_slots_for", "gmc_train_step_f32",
+    "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -45,10 +46,12 @@ class GmcModel(C.Structure):
         ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
         ("dropout_p", C.c_float), ("dropout_seed_lo", C.c_uint32), ("dropout_seed_hi", C.c_uint32),
+        ("W1_slab", C.c_void_p),
     ]
 
 
 _lib: Optional[C.CDLL] = None
+HAS_SLAB = False
 
 
 def _declare(lib: C.CDLL) -> None:
@@ -69,17 +72,28 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_ell_arrange_host.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp]
     if hasattr(lib, "gmc_ell_slots_for"):   # (absent from libraries built before round 2: A/B runs load those)
         lib.gmc_ell_slots_for.argtypes = [i32, vp, i32]
+    # libraries built before the W1 slab copy existed (A/B runs load those) lack the three slab symbols and
+    # take gmc_train_step_f32 without its w1_slab argument: HAS_SLAB tells the engine which form to call
+    global HAS_SLAB
+    HAS_SLAB = hasattr(lib, "gmc_w1_slab_f32")
     lib.gmc_train_step_f32.argtypes = [C.POINTER(GmcBatch), i32, i32, vp, f32, vp, sz, vp, vp, vp, vp, vp, vp,
-                                       C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
+                                       C.c_double, C.c_double, C.c_double, C.c_double, vp] + ([vp, vp] if HAS_SLAB else [vp])
+    if HAS_SLAB:
+        lib.gmc_adam_devstep_model_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.c_double, C.c_double, C.c_double,
+                                                   C.c_double, vp, vp]
+        lib.gmc_w1_slab_floats.argtypes = [i32, i32]
+        lib.gmc_w1_slab_floats.restype = sz
+        lib.gmc_w1_slab_f32.argtypes = [vp, i32, i32, vp, vp]
     lib.gmc_set_fuse.argtypes = [C.c_int]
     lib.gmc_decode_sample_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.gmc_probe_begin.argtypes = [i32]
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
     for name in SYMBOLS:
-        if name == "gmc_ell_slots_for" and not hasattr(lib, name):
+        if name in ("gmc_ell_slots_for", "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32") \
+                and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
-        if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes"):
+        if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes", "gmc_w1_slab_floats"):
             fn.restype = C.c_int
 
 

@@ -89,6 +89,13 @@ typedef struct gmc_model {
      * as the gmc_forward that produced P.  gmc_train_step_f32 has no dropout (it builds its own model). */
     float dropout_p;
     uint32_t dropout_seed_lo, dropout_seed_hi;
+    /* Optional (NULL = not used): a copy of conv1.weight in the slab layout [ceil(F/16)][N][16] (element (r, c) at
+     * ((c/16)*N + r)*16 + c%16, pad columns zero; gmc_w1_slab_floats floats).  The fused layer-1 forward streams the
+     * 16 W1 columns of a slice into LDS per (graph, slice): from this copy a wave's LDS-DMA instruction reads one
+     * contiguous KiB, from the [N,F] layout sixteen 64-byte pieces (8 % of the kernel's time).  The CALLER keeps
+     * it equal to W1: gmc_w1_slab_f32 builds it; gmc_train_step_f32 and gmc_adam_devstep_model_f32 write the
+     * updated W1 to both.  Results do not depend on it (same values, same order of operations). */
+    const float *W1_slab;
 } gmc_model;
 /* gmc_train_fwd_bwd: grad has ONE more float after the N*F + F + F*3 + 3 gradient entries and
  * receives the sum of the batch's per-graph losses there (loss must be non-NULL).  Lets a
@@ -189,6 +196,17 @@ int gmc_adam_devstep_f32(float *param, const float *grad, float *m, float *v, in
                          double beta1, double beta2, double eps, int32_t *step_counter,
                          gmc_stream_t stream);
 
+/* gmc_adam_devstep_f32 over the flat [W1 | b1 | W2 | b2] buffer of an N x F x 3 model; w1_slab (NULL = none)
+ * receives the updated conv1.weight in the layout of gmc_model.W1_slab. */
+int gmc_adam_devstep_model_f32(float *param, const float *grad, float *m, float *v, int32_t N, int32_t F,
+                               float *w1_slab, double lr, double beta1, double beta2, double eps,
+                               int32_t *step_counter, gmc_stream_t stream);
+
+/* floats of, and the launch that builds, the slab copy of conv1.weight [N,F] described at gmc_model.W1_slab
+ * (no counterpart in the reference: a layout the LDS-DMA of the fused forward reads in whole KiB pieces) */
+size_t gmc_w1_slab_floats(int32_t N, int32_t F);
+int gmc_w1_slab_f32(const float *W1, int32_t N, int32_t F, float *slab, gmc_stream_t stream);
+
 /* ---- fused entry points ------------------------------------------------------------ */
 
 /* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
@@ -212,11 +230,13 @@ int gmc_train_fwd_bwd(const gmc_batch *batch, const gmc_model *model, float C, v
  * one sweep over the flat buffers (param/grad/m/v, each N*F + F + F*3 + 3 floats, 16-byte
  * aligned).  The step number lives in device memory as for gmc_adam_devstep_f32, so the call is
  * replay-invariant (hipGraph).  Single-GPU form: with data parallelism the all-reduce has to
- * sit between the gradient and Adam (gmc_train_fwd_bwd + all-reduce + gmc_adam_*). */
+ * sit between the gradient and Adam (gmc_train_fwd_bwd + all-reduce + gmc_adam_*).
+ * w1_slab (NULL = none): the slab copy of conv1.weight (gmc_model.W1_slab), equal to it on entry; the forward
+ * reads it and the Adam sweep writes the updated weights to it as well, so it stays equal. */
 int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, float *param, float C, void *workspace,
                        size_t workspace_bytes, float *P, int32_t *S, float *loss, float *grad, float *m,
                        float *v, double lr, double beta1, double beta2, double eps, int32_t *step_counter,
-                       gmc_stream_t stream);
+                       float *w1_slab, gmc_stream_t stream);
 
 /* Backward for a caller-supplied dLoss/dP (autograd.Function path: callers that build
  * their own loss from GCNSoftmax.forward's output, e.g. the reference's

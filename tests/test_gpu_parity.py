@@ -1056,3 +1056,77 @@ def test_bench_single_rank_over_rccl(pkg):
     assert d["launch"] == "hipGraphs around the eager all-reduce" and s["launch"] == "hipGraph replay"
     assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
     assert d["last_loss"] == s["last_loss"]          # same six graphs, same six steps, integer-valued loss
+
+
+def _slab_of(W1: np.ndarray) -> np.ndarray:
+    """gmc_model.W1_slab: [ceil(F/16)][N][16], pad columns zero."""
+    N, F = W1.shape
+    pad = np.zeros((N, (F + 15) // 16 * 16), np.float32)
+    pad[:, :F] = W1
+    return pad.reshape(N, -1, 16).transpose(1, 0, 2).copy()
+
+
+@pytest.mark.parametrize("hidden", [500, 72])      # 72 = 4.5 slabs: a partly padded last slab
+def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden):
+    """The slab copy of conv1.weight (gmc_model.W1_slab): gmc_w1_slab_f32 lays it out as documented; a trainer
+    whose fused forward reads it and whose Adam sweep keeps it current ends up with BIT-identical parameters,
+    losses and copy (the copy changes where the W1 tile is fetched from, not what is computed) - on one GPU
+    (whole-step hipGraph) and on the data-parallel step sequence (graphs either side of the all-reduce)."""
+    specs = [(1000, 7, 61), (700, 7, 62), (1000, 7, 63), (520, 6, 64)]
+    ds = util.product_dataset(specs)
+
+    class WithoutFusedStep:           # an engine that offers only what the N > 1 branch uses
+        def __init__(self, eng):
+            self._eng = eng
+
+        def __getattr__(self, name):
+            if name == "train_step":
+                raise AttributeError(name)
+            return getattr(self._eng, name)
+
+    for dp_sequence in (False, True):
+        runs = []
+        for slab in (True, False):
+            T, cfg, net, embed, opt, params = model_and_params(pkg, hidden, seed=9)
+            eng = net.engine()
+            eng.slab_enabled = slab and eng.slab_enabled
+            tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=2, engine=WithoutFusedStep(eng) if dp_sequence else eng)
+            if dp_sequence:
+                tr.dp = True                          # the all-reduce itself is a no-op without a process group
+            losses = [tr.epoch(ds) for _ in range(3)]
+            torch.cuda.synchronize()
+            if slab:
+                assert eng.w1_slab is not None and (tr._graph is not None or tr._dp_graph is not None)
+                got = eng.w1_slab.cpu().numpy().reshape(-1, 1000, 16)
+                assert np.array_equal(got, _slab_of(eng.views()["conv1.weight"].cpu().numpy()))   # kept current
+            runs.append((losses, eng.flat.cpu().numpy().copy()))
+        assert runs[0][0] == runs[1][0]
+        assert np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_w1_slab_copy_follows_torch_writes(pkg):
+    """Anything torch writes into the parameters between two steps of the fused trainer (optimizer surgery,
+    load_state_dict, an in-place edit) must reach the next forward: the engine re-builds the slab copy when a
+    version counter of the flat buffer or of an adopted parameter moved."""
+    ds = util.product_dataset([(1000, 7, 71), (640, 7, 72)])
+    runs = []
+    for slab in (True, False):
+        T, cfg, net, embed, opt, params = model_and_params(pkg, 64, seed=3)
+        eng = net.engine()
+        eng.slab_enabled = slab and eng.slab_enabled
+        tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=2)
+        out = [tr.epoch(ds), tr.epoch(ds)]
+        with torch.no_grad():
+            net.conv1.weight.mul_(0.5)                               # through the nn.Parameter
+        out.append(tr.epoch(ds))
+        eng.views()["conv1.weight"][:300].add_(0.01)                 # through a view of the flat buffer
+        out.append(tr.epoch(ds))
+        state = {k: v.clone() for k, v in net.state_dict().items()}
+        out.append(tr.epoch(ds))
+        net.load_state_dict(state)                                   # roll one step back
+        out.append(tr.epoch(ds))
+        torch.cuda.synchronize()
+        assert out[5] == out[4]                                      # the same step from the same weights
+        runs.append((out, eng.flat.cpu().numpy().copy()))
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(runs[0][1], runs[1][1])
