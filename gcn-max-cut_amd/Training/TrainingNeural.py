@@ -385,6 +385,13 @@ class FusedTrainer:
         self._loss_host = (torch.empty_like(self._loss_slots, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         self._loss_host_np = self._loss_host.numpy() if self._loss_host is not None else None   # (shares the pinned memory)
+        # device-side address of that pinned buffer: the captured steps store their per-graph losses straight
+        # into it (one system-scope store each, as soon as the value is final), so the host has a step's loss
+        # while its backward is still running and no copy node trails the graph (GCN_MAXCUT_LOSS_ZEROCOPY=0: copy)
+        self._loss_host_dev = None
+        if (self._loss_host is not None and hasattr(self.eng, "lib") and self._poll
+                and os.environ.get("GCN_MAXCUT_LOSS_ZEROCOPY", "1") != "0"):
+            self._loss_host_dev = hip.mapped_ptr(self._loss_host)
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         self._step_host_np = self._step_host.numpy() if self._step_host is not None else None
@@ -605,10 +612,13 @@ class FusedTrainer:
     def _enqueue_epoch(self, with_readback: bool = False) -> None:
         eng, cfg = self.eng, self.config
         lr, betas, eps = self._hyper()
+        direct = self._loss_host_dev if with_readback else None
+        row_bytes = self._loss_slots.shape[1] * 4 if self._loss_slots is not None else 0
         for i, batch in enumerate(self._batches):
+            extra = {"loss_ptr": direct + i * row_bytes} if direct else {}
             eng.train_step(batch, lr, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]), betas=betas, eps=eps,
-                           ws=self._ws, **self._slab)
-        if with_readback and self._loss_host is not None:
+                           ws=self._ws, **self._slab, **extra)
+        if with_readback and self._loss_host is not None and not direct:
             self._loss_host.copy_(self._loss_slots, non_blocking=True)
 
     def _replay_epoch(self) -> None:

@@ -280,6 +280,13 @@ extern "C" const char *gmc_error_string(int code) {
     }
 }
 
+// device-side address of pinned (hipHostMalloc / hipHostRegister) host memory, for callers that let the kernels
+// write a result - the per-graph losses - straight into host memory they poll
+extern "C" int gmc_host_device_pointer(void *pinned_host, void **device_ptr) {
+    if (!pinned_host || !device_ptr) return GMC_ERR_NULL;
+    return (int)hipHostGetDevicePointer(device_ptr, pinned_host, 0);
+}
+
 extern "C" size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training) {
     if (!batch || !model) return 0;
     return carve(batch, model, training, nullptr).bytes;

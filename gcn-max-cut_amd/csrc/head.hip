@@ -185,7 +185,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     }
     block_sum4(acc, red);  // contains a __syncthreads(): sA writes are visible after it
     if (threadIdx.x == 0) {
-        if (a.loss) a.loss[g] = -a.C * (acc[0] * 0.5f);
+        // one system-scope store: `loss` may be pinned host memory the caller watches (the value is final here,
+        // long before the launch - let alone a graph of launches - ends)
+        if (a.loss) __hip_atomic_store(a.loss + g, -a.C * (acc[0] * 0.5f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (train && a.db2part) {
             a.db2part[g * 3] = acc[1]; a.db2part[g * 3 + 1] = acc[2]; a.db2part[g * 3 + 2] = acc[3];
         }

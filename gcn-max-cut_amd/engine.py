@@ -190,10 +190,13 @@ class FusedEngine:
         return P, S, loss
 
     def train_step(self, batch: GraphBatch, lr: float, C_: float = 1.0, out=None, betas=(0.9, 0.999),
-                   eps: float = 1e-8, ws: Optional[torch.Tensor] = None, slab: bool = False):
+                   eps: float = 1e-8, ws: Optional[torch.Tensor] = None, slab: bool = False,
+                   loss_ptr: Optional[int] = None):
         """One whole optimizer step (forward, loss, backward, fused gradient fold + Adam) - the
         single-GPU form of the loop body of train_single_epoch (TrainingNeural.py:373-386).
-        Replay-invariant: the step number is read from / advanced in device memory."""
+        Replay-invariant: the step number is read from / advanced in device memory.  ``loss_ptr``: device-side
+        address of pinned host memory (``hip.mapped_ptr``) that receives the per-graph losses instead of
+        ``out[2]`` - each is stored as soon as it is final, before the backward kernels run."""
         ws, nbytes = (ws, ws.numel()) if ws is not None else self._workspace(batch, True)
         if out is None:
             P = torch.empty((batch.R, 3), dtype=torch.float32, device=self.device)
@@ -203,9 +206,9 @@ class FusedEngine:
             P, S, loss = out
         tail = (self.ensure_slab() if slab else None, hip.stream()) if hip.HAS_SLAB else (hip.stream(),)
         rc = self.lib.gmc_train_step_f32(batch.ref(), self.N, self.F, hip.ptr(self.flat), C_, hip.ptr(ws), nbytes,
-                                         hip.ptr(P), hip.ptr(S), hip.ptr(loss), hip.ptr(self.grad), hip.ptr(self.m),
-                                         hip.ptr(self.v), lr, betas[0], betas[1], eps, hip.ptr(self.step_dev),
-                                         *tail)
+                                         hip.ptr(P), hip.ptr(S), loss_ptr or hip.ptr(loss), hip.ptr(self.grad),
+                                         hip.ptr(self.m), hip.ptr(self.v), lr, betas[0], betas[1], eps,
+                                         hip.ptr(self.step_dev), *tail)
         if not slab:
             self._slab_sig = None   # W1 moved, the copy did not
         hip.check(rc, "gmc_train_step_f32")

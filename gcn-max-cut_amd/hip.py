@@ -20,7 +20,7 @@ SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
     "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_ell_slots_for", "gmc_train_step_f32",
-    "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32",
+    "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32", "gmc_host_device_pointer",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -88,8 +88,11 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_decode_sample_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.gmc_probe_begin.argtypes = [i32]
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
+    if hasattr(lib, "gmc_host_device_pointer"):
+        lib.gmc_host_device_pointer.argtypes = [vp, C.POINTER(vp)]
     for name in SYMBOLS:
-        if name in ("gmc_ell_slots_for", "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32") \
+        if name in ("gmc_ell_slots_for", "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32",
+                    "gmc_host_device_pointer") \
                 and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)
@@ -139,6 +142,18 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
     return t.data_ptr()
+
+
+def mapped_ptr(t: torch.Tensor) -> Optional[int]:
+    """Device-side address of a PINNED host tensor (kernels may store into it; the host polls it), or None when
+    the library / runtime cannot map it."""
+    lib = load()
+    if not (t.device.type == "cpu" and t.is_pinned() and t.is_contiguous() and hasattr(lib, "gmc_host_device_pointer")):
+        return None
+    out = C.c_void_p()
+    if lib.gmc_host_device_pointer(C.c_void_p(t.data_ptr()), C.byref(out)) != 0 or not out.value:
+        return None
+    return int(out.value)
 
 
 def stream() -> int:

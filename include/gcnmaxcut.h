@@ -209,6 +209,13 @@ int gmc_w1_slab_f32(const float *W1, int32_t N, int32_t F, float *slab, gmc_stre
 
 /* ---- fused entry points ------------------------------------------------------------ */
 
+/* `loss` of the entry points below may be device memory or PINNED HOST memory mapped into the device: each
+ * graph's value is written with one system-scope store as soon as it is final (by the loss kernel, before the
+ * backward kernels of the same call run), so a host thread watching that memory has the step's loss while the
+ * rest of the step is still executing - the reference reads loss.item() every step (TrainingNeural.py:387-388).
+ * gmc_host_device_pointer: the device-side address of such memory (hipHostGetDevicePointer; > 0 = hipError_t). */
+int gmc_host_device_pointer(void *pinned_host, void **device_ptr);
+
 /* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
 size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training);
 
