@@ -395,6 +395,12 @@ class FusedTrainer:
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         self._step_host_np = self._step_host.numpy() if self._step_host is not None else None
+        # data-parallel steps: the all-reduced loss of a step (the gradient's tail slot) is published to this pinned
+        # buffer by a one-wave launch BEFORE the step's Adam launches, so the host has it while Adam still runs
+        self._step_host_dev = None
+        if (self._step_host is not None and hasattr(self.eng, "publish") and self._poll
+                and os.environ.get("GCN_MAXCUT_LOSS_ZEROCOPY", "1") != "0"):
+            self._step_host_dev = hip.mapped_ptr(self._step_host)
         # private scratch, sized for the largest step: the engine's own scratch is re-allocated whenever a
         # later call (evaluate_model on a bigger batch, another trainer) needs more, which would leave a
         # captured hipGraph replaying into freed memory
@@ -447,6 +453,7 @@ class FusedTrainer:
             eng.set_dropout(0.0)
             return float(self._step_loss.cpu().numpy().sum(dtype=np.float64))
         use_graph = self._use_graph()
+        publish = None
         poll = use_graph and self._poll and self._loss_host_np is not None
         if poll:
             self._loss_host_np.fill(np.nan)   # sentinel: every loss is a finite number (<= 0)
@@ -466,6 +473,9 @@ class FusedTrainer:
                 eng.sync_step_dev()
                 if self._slab:
                     eng.ensure_slab()   # (a launch only when torch wrote the parameters since the last step)
+            publish = self._step_host_dev if self.dp else None
+            if publish:
+                self._step_host_np.fill(np.nan)   # sentinel: every step loss is a finite number
             for i, batch in enumerate(self._batches):
                 if batch.B == 0:
                     # this rank's shard of the step is empty (last group smaller than the world): it
@@ -479,7 +489,9 @@ class FusedTrainer:
                                       **({"ws": self._ws} if self._ws is not None else {}), **self._slab)
                 if self.dp:
                     eng.allreduce_grad()               # ONE RCCL all-reduce of [gradient | loss] per step, eager
-                    if i != last:                      # the last step's slot is read in place below
+                    if publish:                        # the step's loss -> pinned host slot i, ahead of Adam
+                        eng.publish(tail, publish + 4 * i)
+                    elif i != last:                    # the last step's slot is read in place below
                         self._step_loss[i:i + 1].copy_(tail)
                 if graphs is not None:
                     graphs[1].replay()                 # Adam, step number read from / advanced in device memory
@@ -492,9 +504,11 @@ class FusedTrainer:
                 return 0.0
             if self._step_host is not None:
                 host = self._step_host_np
-                if self._poll:
+                if self._poll and not publish:
                     host.fill(np.nan)   # sentinel: every step loss is a finite number
-                if last == 0:   # one step per epoch: its loss goes from the gradient's tail slot to the host
+                if publish:
+                    pass            # every step has already sent its loss
+                elif last == 0:   # one step per epoch: its loss goes from the gradient's tail slot to the host
                     self._step_host.copy_(tail, non_blocking=True)
                 else:
                     self._step_loss[last:last + 1].copy_(tail)

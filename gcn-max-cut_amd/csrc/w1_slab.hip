@@ -35,3 +35,21 @@ extern "C" int gmc_w1_slab_f32(const float *W1, int32_t N, int32_t F, float *sla
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }
+
+namespace {
+__global__ __launch_bounds__(64) void publish_kernel(const float *src, int n, float *dst) {
+    for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+// n floats of device memory -> pinned host memory (its device-side address), one system-scope store each: what a
+// data-parallel rank does with the all-reduced loss of a step (the slot after the gradient), so that the host
+// has it while Adam is still running.  One tiny launch instead of a copy-engine transfer.
+extern "C" int gmc_publish_f32(const float *src, int32_t n, float *pinned_dst, gmc_stream_t stream) {
+    if (!src || !pinned_dst) return GMC_ERR_NULL;
+    if (n < 0) return GMC_ERR_SHAPE;
+    if (n == 0) return GMC_OK;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), src, (int)n, pinned_dst);
+    GMC_LAUNCH_CHECK();
+    return GMC_OK;
+}

@@ -276,6 +276,12 @@ class FusedEngine:
         self._slab_sig = None   # (a collective writes through raw pointers: no version counter moves)
         self.sync_step_dev()
 
+    def publish(self, src: torch.Tensor, pinned_dst: int) -> None:
+        """``src`` (device floats) -> pinned host memory at its device-side address ``pinned_dst``
+        (``hip.mapped_ptr``), one system-scope store per value, on the current stream."""
+        rc = self.lib.gmc_publish_f32(hip.ptr(src), src.numel(), pinned_dst, hip.stream())
+        hip.check(rc, "gmc_publish_f32")
+
     def allreduce_grad(self, local_loss_sum: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """One RCCL all-reduce (sum) of [grad | loss] over xGMI when torch.distributed is up."""
         if local_loss_sum is not None:

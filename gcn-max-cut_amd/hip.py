@@ -20,7 +20,7 @@ SYMBOLS = (
     "gmc_version", "gmc_error_string", "gmc_spmm_f32", "gmc_dense_hw2_f32", "gmc_head_f32",
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
     "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_ell_slots_for", "gmc_train_step_f32",
-    "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32", "gmc_host_device_pointer",
+    "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32", "gmc_host_device_pointer", "gmc_publish_f32",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -90,9 +90,10 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
     if hasattr(lib, "gmc_host_device_pointer"):
         lib.gmc_host_device_pointer.argtypes = [vp, C.POINTER(vp)]
+        lib.gmc_publish_f32.argtypes = [vp, i32, vp, vp]
     for name in SYMBOLS:
         if name in ("gmc_ell_slots_for", "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32",
-                    "gmc_host_device_pointer") \
+                    "gmc_host_device_pointer", "gmc_publish_f32") \
                 and not hasattr(lib, name):
             continue
         fn = getattr(lib, name)

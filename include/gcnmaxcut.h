@@ -215,6 +215,10 @@ int gmc_w1_slab_f32(const float *W1, int32_t N, int32_t F, float *slab, gmc_stre
  * rest of the step is still executing - the reference reads loss.item() every step (TrainingNeural.py:387-388).
  * gmc_host_device_pointer: the device-side address of such memory (hipHostGetDevicePointer; > 0 = hipError_t). */
 int gmc_host_device_pointer(void *pinned_host, void **device_ptr);
+/* n device floats -> pinned host memory (device-side address), one system-scope store each: how a data-parallel
+ * rank hands the all-reduced loss of a step (the slot after the gradient, GMC_MODEL_GRAD_TAIL) to its host
+ * thread before the optimizer kernels of that step run. */
+int gmc_publish_f32(const float *src, int32_t n, float *pinned_dst, gmc_stream_t stream);
 
 /* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
 size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training);
