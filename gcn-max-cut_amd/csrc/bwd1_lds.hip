@@ -185,7 +185,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         if (threadIdx.x < kPadRows * FS) buf[n * FS + threadIdx.x] = 0.f;
     };
     auto fetch_tile = [&](int r0, int n) {  // H tile of the graph at rows [r0, r0+n) -> bufA
-        dma_tile<FS, ACC>(Hs + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+        dma_tile<FS, ACC, true>(Hs + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);   // H: read once
     };
 
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
@@ -295,7 +295,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
     auto fetch = [&](int r0, int n) {  // H tile -> bufA (DMA); neighbour table -> registers
-        dma_tile<FS, ACC>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);
+        dma_tile<FS, ACC, true>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);   // H: read once
         dma_row_consts(a.GY2, r0, n, gyl);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll

@@ -185,7 +185,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                 const gmc::v2f yhi = gmc::pk_fma((gmc::v2f){acc.z, acc.w}, s2, bhi);
                 float4 y;
                 y.x = gmc::relu1(ylo.x); y.y = gmc::relu1(ylo.y); y.z = gmc::relu1(yhi.x); y.w = gmc::relu1(yhi.y);  // F.relu, :81
-                if (!ABL(2)) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+                if (!ABL(2)) store_nt(ydst + (long)(r0 + l) * a.y_rs, y);
                 if (ABL(3)) { z2[k] += y.x + y.y + y.z + y.w; return; }
                 // (H o dinv) @ W2 for my columns (:83; dinv applied at the flush): 4 packed + 4 scalar FMAs
                 z01[k] = gmc::pk_fma(gmc::splat2(y.x), w01[0], z01[k]); z2[k] = fmaf(y.x, w2c[0], z2[k]);

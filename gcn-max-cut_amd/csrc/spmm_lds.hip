@@ -63,7 +63,7 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
     const float *src0 = a.X + (SHARED ? 0L : (long)r0 * a.x_rs) + 4 * q;
 
-    dma_tile<FS, ACC>(src0 + s_beg * a.x_ss - max(0, s_beg * FS + 4 * q - (a.F - 4)), a.x_rs, n, true, lrow, lds);
+    dma_tile<FS, ACC, !SHARED>(src0 + s_beg * a.x_ss - max(0, s_beg * FS + 4 * q - (a.F - 4)), a.x_rs, n, true, lrow, lds);
 
     // prologue: every global read is issued before the first use, so the workgroup pays one memory
     // latency (not one per table) before its first gather
@@ -138,7 +138,7 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
             float4 y;
             y.x = gmc::max1(fmaf(acc.x, sk, bias.x), lo); y.y = gmc::max1(fmaf(acc.y, sk, bias.y), lo);
             y.z = gmc::max1(fmaf(acc.z, sk, bias.z), lo); y.w = gmc::max1(fmaf(acc.w, sk, bias.w), lo);
-            if (col_on) *reinterpret_cast<float4 *>(ydst + (long)(r0 + l) * a.y_rs) = y;
+            if (col_on) store_nt(ydst + (long)(r0 + l) * a.y_rs, y);
             if (EPI) {
                 zr[k][0] += y.x * wa.x + y.y * wa.w + y.z * wb.z + y.w * wc.y;
                 zr[k][1] += y.x * wa.y + y.y * wb.x + y.z * wb.w + y.w * wc.z;
@@ -150,7 +150,7 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     // so the tile never holds stale or uninitialised (possibly non-finite) values
     auto prefetch = [&](int s, int into) {
         const int back = max(0, s * FS + 4 * q - (a.F - 4));  // columns past the last valid group
-        dma_tile<FS, ACC>(src0 + s * a.x_ss - back, a.x_rs, n, true, lrow, lds + into * TF);
+        dma_tile<FS, ACC, !SHARED>(src0 + s * a.x_ss - back, a.x_rs, n, true, lrow, lds + into * TF);   // batch rows: read once (nt)
     };
 
     // Steady state: the DMA of slice s+1 is issued first, the LDS gather of slice s runs while it is
@@ -219,7 +219,7 @@ __global__ GMC_LDS_BOUNDS void dw1_lds_kernel(Dw1TileArgs a) {
     auto fetch = [&](int g, int into) {  // tile slice -> LDS buffer `into` (DMA); neighbour table -> registers
         const int r0 = a.b.goff[g];
         const int n = a.b.goff[g + 1] - r0;
-        dma_tile<FS, ACC>(a.U + (long)r0 * a.u_rs + (long)s * a.u_ss + 4 * q, a.u_rs, n, col_on, lrow, lds + into * TF);
+        dma_tile<FS, ACC, true>(a.U + (long)r0 * a.u_rs + (long)s * a.u_ss + 4 * q, a.u_rs, n, col_on, lrow, lds + into * TF);   // U: read once
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
