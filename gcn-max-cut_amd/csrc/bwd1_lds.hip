@@ -150,6 +150,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
     int chunk, s;
+    MARK(0);
     tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
@@ -198,6 +199,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     dma_wait();
     __syncthreads();
     STAMP_DECL;
+    MARK(1);
     for (int g = g0; g < g1; ++g) {
         const int cur = (g - g0) & 1;
         const float *gyl = cur ? gy1 : gy0;
@@ -256,6 +258,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         r0 = r0n; n = nn; nn = n2;
     }
     STAMP_FLUSH;
+    MARK(2);
     if (col_on) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -264,7 +267,9 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         }
     }
     __syncthreads();  // gather #2 of the last graph is done everywhere: bufB becomes the fold area
+    // (an LDS-only barrier here - not waiting for the dW1 stores above - measured no different)
     col_epilogue<Q>(cs, red, a.colpart, chunk, s, FS, a.F);
+    MARK(3);
 }
 
 // ---- 16-slot tables (degree 9..16): neighbour table in LDS, three barriers per graph ----------------

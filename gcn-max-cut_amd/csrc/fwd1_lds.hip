@@ -22,6 +22,7 @@ namespace {
 template <int FS, int W, int ACC, bool HAS_VAL, int NS>
 __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     STAMP_DECL;
+    MARK(0);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
@@ -55,6 +56,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
         if (c_on) cst[cc] = c;
     }
 
+    MARK(1);
     for (int it = it0; it < it1;) {
         const int g = it / a.groups;
         const int it_end = min(it1, (g + 1) * a.groups);           // my items of graph g
@@ -212,6 +214,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     }
     STAMP(7);  // epilogue
     STAMP_FLUSH;
+    MARK(3);
 }
 
 template <int FS, int W>

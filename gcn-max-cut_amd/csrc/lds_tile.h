@@ -26,7 +26,16 @@ static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per trans
         if (threadIdx.x == 0 && blockIdx.x < 4096)                                     \
             for (int i = 0; i < 12; ++i) g_stamps[blockIdx.x * 16 + i] = st_acc[i];    \
     } while (0)
+// wall-clock marks (s_memrealtime: one 100 MHz counter for the whole chip) in slots 12..15 of the workgroup:
+// kernel entry, tile loop start, tile loop end, kernel exit - where a launch's fixed time goes
+#define MARK(i)                                                                                  \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 16 + 12 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
 #else
+#define MARK(i)
 #define STAMP_DECL
 #define STAMP(i)
 #define STAMP_FLUSH

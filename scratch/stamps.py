@@ -25,3 +25,22 @@ eng.train_fwd_bwd(batch); torch.cuda.synchronize()
 b = read(256, 'bwd')
 tot = b[:, :11].sum(1).mean()
 print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})
+
+def marks(x, label):
+    m = x[:, 12:16] * 10.0 / 1e3          # 100 MHz ticks -> us
+    t0 = m[:, 0].min()
+    ent, l0, l1, ex = m[:, 0] - t0, m[:, 1] - t0, m[:, 2] - t0, m[:, 3] - t0
+    q = lambda v: "min %.1f med %.1f max %.1f" % (v.min(), np.median(v), v.max())
+    print(label, "us since the first workgroup's entry | entry:", q(ent), "| loop start:", q(l0), "| loop end:", q(l1) if l1.max() > 0 else "-", "| exit:", q(ex))
+    print(label, "per workgroup: prologue", q(l0 - ent), "| loop", q((l1 if l1.max() > 0 else ex) - l0), "| epilogue", q(ex - l1) if l1.max() > 0 else "-")
+marks(a, "fwd1")
+marks(b, "bwd1")
+mb = b[:, 12:16] * 10.0 / 1e3
+loop = mb[:, 2] - mb[:, 1]
+blk = np.arange(256)
+print("bwd1 loop us by chunk (= XCD = block & 7):", [round(float(np.median(loop[(blk & 7) == c])), 1) for c in range(8)])
+print("bwd1 loop us by slice (= block >> 3), first 8 / last 4:", [round(float(np.median(loop[(blk >> 3) == s])), 1) for s in list(range(8)) + [28, 29, 30, 31]])
+print("bwd1 prologue us by chunk:", [round(float(np.median((mb[:, 1] - mb[:, 0])[(blk & 7) == c])), 1) for c in range(8)])
+ma = a[:, 12:16] * 10.0 / 1e3
+lf = ma[:, 3] - ma[:, 1]
+print("fwd1 loop us by XCD (block & 7):", [round(float(np.median(lf[(blk & 7) == c])), 1) for c in range(8)], "by block/32:", [round(float(np.median(lf[(blk >> 5) == c])), 1) for c in range(8)])
