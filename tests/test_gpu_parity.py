@@ -1053,7 +1053,7 @@ def test_bench_single_rank_over_rccl(pkg):
         lines[tag] = json.loads(line)
     d, s = lines["rccl"], lines["single"]
     assert d["backend"] == "nccl" and d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"
-    assert d["launch"] == "hipGraphs around the eager all-reduce" and s["launch"] == "hipGraph replay"
+    assert d["launch"] == "hipGraphs around the eager all-reduce" and s["launch"].startswith("eager launches queued")
     assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
     assert d["last_loss"] == s["last_loss"]          # same six graphs, same six steps, integer-valued loss
 
