@@ -340,10 +340,41 @@ def test_step_gradients_match_oracle(pkg, hidden, specs):
     eng.grad.fill_(float("nan"))       # read before it is written in the same step
     P, S, loss = eng.train_fwd_bwd(batch, 1.0)
     ct = CO.CTrainer(params)
-    ref_loss = ct.step(util.csrs_of(ds))
-    assert np.array_equal(loss.cpu().numpy(), ref_loss)
-    assert float(eng.grad[eng.count]) == float(ref_loss.sum())   # GMC_MODEL_GRAD_TAIL: the loss rides behind the gradient
-    ref = flat_ref_grads(ct)
+    csrs = util.csrs_of(ds)
+    ref_loss = ct.step(csrs)
+    loss_np, S_np = loss.cpu().numpy(), S.cpu().numpy()
+    if not np.array_equal(loss_np, ref_loss):
+        # A graph whose loss differs decoded some row differently.  That is legitimate only on a near-tie (the
+        # summation order of the kernels is not the oracle's: top-2 margin inside fp32 noise); the gradient of
+        # such a graph is then the oracle's backward for the partition the KERNELS chose, which is what is built
+        # here: same forward, GP from the kernels' S, same backward.
+        W = [params[k] for k in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")]
+        acc = [np.zeros_like(w) for w in W]
+        off = 0
+        for i, (rp, cl, vl) in enumerate(csrs):
+            n = len(rp) - 1
+            f = CO.forward(rp, cl, vl, *W)
+            ref_s = f["P"].argmax(1); ref_s[:3] = [0, 1, 2]
+            s_i = S_np[off:off + n]
+            diff = np.nonzero(s_i != ref_s)[0]
+            if diff.size == 0:
+                assert loss_np[i] == ref_loss[i], i
+            else:
+                srt = np.sort(f["P"][diff].astype(np.float64), axis=1)
+                assert (srt[:, 2] - srt[:, 1]).max() < 1e-6, (i, diff, srt)
+            wv = np.ones(len(cl), np.float32) if vl is None else vl
+            rows = np.repeat(np.arange(n), np.diff(rp))
+            GP = np.zeros((n, 3), np.float32)
+            np.add.at(GP, (rows, s_i[cl]), wv)                     # GP = C * A_val @ onehot(S), C = 1
+            cut = 0.5 * float(wv[s_i[rows] != s_i[cl]].sum())
+            assert loss_np[i] == -cut, i                            # loss == -cut of the partition the kernels chose
+            for a_, d_ in zip(acc, CO.backward(rp, cl, vl, W[0].shape[0], W[2], f["H"], f["P"], GP)):
+                a_ += d_
+            off += n
+        ref = dict(zip(("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"), [a_.ravel() for a_ in acc]))
+    else:
+        ref = flat_ref_grads(ct)
+    assert float(eng.grad[eng.count]) == float(loss_np.sum())   # GMC_MODEL_GRAD_TAIL: the loss rides behind the gradient
     for k, g in eng.views(eng.grad).items():
         g, r = g.cpu().numpy().ravel(), ref[k]
         assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
