@@ -55,3 +55,24 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower() or f == "never", (dirpath, f)
+
+
+def test_argument_errors_need_no_gpu(built):
+    """The entry points added for the slab copy of W1 / host-memory losses reject bad arguments with their status
+    codes before any HIP call (so this runs without a GPU); sizes come from a host function."""
+    import ctypes as C
+    lib = built.hip.load()
+    assert lib.gmc_w1_slab_floats(1000, 500) == 32 * 1000 * 16        # [ceil(F/16)][N][16]
+    assert lib.gmc_w1_slab_floats(1000, 72) == 5 * 1000 * 16
+    assert lib.gmc_w1_slab_floats(0, 500) == 0
+    null, some = C.c_void_p(None), C.c_void_p(4096)                    # (never dereferenced: the calls fail first)
+    assert lib.gmc_w1_slab_f32(null, 1000, 500, some, None) == -1      # GMC_ERR_NULL
+    assert lib.gmc_w1_slab_f32(some, 1000, 501, some, None) == -2      # GMC_ERR_SHAPE: F % 4
+    assert lib.gmc_w1_slab_f32(some, 1000, 500, C.c_void_p(4100), None) == -4   # GMC_ERR_ALIGN
+    assert lib.gmc_publish_f32(null, 4, some, None) == -1
+    assert lib.gmc_publish_f32(some, -1, some, None) == -2
+    assert lib.gmc_publish_f32(some, 0, some, None) == 0               # nothing to do, nothing launched
+    assert lib.gmc_host_device_pointer(null, C.byref(C.c_void_p())) == -1
+    assert lib.gmc_adam_devstep_model_f32(some, some, some, some, 1000, 501, null, 1e-3, 0.9, 0.999, 1e-8, some, None) == -2
+    assert lib.gmc_adam_devstep_model_f32(some, some, some, some, 1000, 500, C.c_void_p(4100), 1e-3, 0.9, 0.999, 1e-8,
+                                          some, None) == -4

@@ -1161,3 +1161,44 @@ def test_w1_slab_copy_follows_torch_writes(pkg):
         runs.append((out, eng.flat.cpu().numpy().copy()))
     assert runs[0][0] == runs[1][0]
     assert np.array_equal(runs[0][1], runs[1][1])
+
+
+def test_slab_and_host_memory_entry_points_directly(pkg):
+    """The C ABI of the round-2 additions, called directly: gmc_w1_slab_f32 (layout), gmc_adam_devstep_model_f32
+    (== gmc_adam_devstep_f32 on the parameters, and the slab copy follows), gmc_host_device_pointer +
+    gmc_publish_f32 (device floats land in pinned host memory the host can read after the stream is idle)."""
+    import ctypes as C
+    lib, hip = pkg.hip.load(), pkg.hip
+    N, F = 1000, 72
+    count = N * F + F + 3 * F + 3
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(count, generator=g).cuda()
+    grad = (0.1 * torch.randn(count, generator=g)).cuda()
+    slab = torch.empty(int(lib.gmc_w1_slab_floats(N, F)), device="cuda")
+    st = hip.stream()
+    assert lib.gmc_w1_slab_f32(hip.ptr(p0), N, F, hip.ptr(slab), st) == 0
+    assert np.array_equal(slab.cpu().numpy().reshape(-1, N, 16), _slab_of(p0[:N * F].view(N, F).cpu().numpy()))
+    runs = []
+    for with_slab in (False, True):
+        p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+        step = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for _ in range(3):
+            if with_slab:
+                rc = lib.gmc_adam_devstep_model_f32(hip.ptr(p), hip.ptr(grad), hip.ptr(m), hip.ptr(v), N, F, hip.ptr(slab),
+                                                    1e-3, 0.9, 0.999, 1e-8, hip.ptr(step), st)
+            else:
+                rc = lib.gmc_adam_devstep_f32(hip.ptr(p), hip.ptr(grad), hip.ptr(m), hip.ptr(v), count, 1e-3, 0.9, 0.999,
+                                              1e-8, hip.ptr(step), st)
+            assert rc == 0
+        assert int(step.item()) == 3
+        runs.append(p.cpu().numpy())
+    assert np.array_equal(runs[0], runs[1])
+    assert np.array_equal(slab.cpu().numpy().reshape(-1, N, 16), _slab_of(runs[1][:N * F].reshape(N, F)))
+    host = torch.full((8,), float("nan")).pin_memory()
+    dev = hip.mapped_ptr(host)
+    assert dev, "pinned host memory must be mapped into the device"
+    src = torch.arange(8, dtype=torch.float32, device="cuda") - 3.5
+    assert lib.gmc_publish_f32(hip.ptr(src), 8, dev, st) == 0
+    torch.cuda.current_stream().synchronize()
+    assert np.array_equal(host.numpy(), src.cpu().numpy())
+    assert hip.mapped_ptr(torch.zeros(4)) is None      # pageable memory: refused, the trainer then copies instead
