@@ -1202,3 +1202,32 @@ def test_slab_and_host_memory_entry_points_directly(pkg):
     torch.cuda.current_stream().synchronize()
     assert np.array_equal(host.numpy(), src.cpu().numpy())
     assert hip.mapped_ptr(torch.zeros(4)) is None      # pageable memory: refused, the trainer then copies instead
+
+
+def test_one_step_epochs_same_result_on_every_launch_path(pkg, monkeypatch):
+    """One batched step per epoch - the bench workload's shape - through the three launch paths: eager launches
+    with the losses stored straight into pinned host memory (default), a graph replay per step, and plain eager
+    launches with a device loss buffer, a copy and a stream synchronisation.  Same losses, bit-identical models."""
+    specs = [(1000, 7, 91), (640, 7, 92), (1000, 7, 93)]
+    ds = util.product_dataset(specs)
+    runs = {}
+    for path, env in (("direct", {}), ("graph", {"GCN_MAXCUT_EAGER_SINGLE_STEP": "0"}),
+                      ("copy", {"GCN_MAXCUT_LOSS_ZEROCOPY": "0", "GCN_MAXCUT_POLL_LOSS": "0", "GCN_MAXCUT_HIPGRAPH": "0"})):
+        for k in ("GCN_MAXCUT_EAGER_SINGLE_STEP", "GCN_MAXCUT_LOSS_ZEROCOPY", "GCN_MAXCUT_POLL_LOSS", "GCN_MAXCUT_HIPGRAPH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        T, cfg, net, embed, opt, params = model_and_params(pkg, 128, seed=17)
+        tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=len(specs))
+        losses = [tr.epoch(ds) for _ in range(6)]
+        torch.cuda.synchronize()
+        if path == "direct":
+            assert tr._graph is None and tr._loss_host_dev is not None
+        elif path == "graph":
+            assert tr._graph is not None
+        else:
+            assert tr._graph is None and tr._loss_host_dev is None
+        runs[path] = (losses, net.engine().flat.cpu().numpy().copy())
+    for path in ("graph", "copy"):
+        assert runs[path][0] == runs["direct"][0], path
+        assert np.array_equal(runs[path][1], runs["direct"][1]), path
