@@ -203,16 +203,6 @@ class BatchArrays:
                 hip.check(rc, "gmc_ell_arrange_host")
                 # 7 when no row of the batch has more than 7 neighbours: slot 7 of every row is then padding
                 ell_slots = int(lib.gmc_ell_slots_for(R, ptr(rowptr), W)) if hasattr(lib, "gmc_ell_slots_for") else 0
-                if os.environ.get("GMC_EXP_CONFLICT_FREE") == "1" and W == 8:   # TIMING EXPERIMENT ONLY: wrong results
-                    rank = np.array([0, 0, 1, 1, 2, 2, 3, 3, 0, 0, 1, 1, 2, 2, 3, 3])   # rank of a row inside its LDS-cycle group
-                    rank[[0, 3, 5, 6]] = [0, 1, 2, 3]; rank[[1, 2, 4, 7]] = [0, 1, 2, 3]
-                    rank[[8, 11, 13, 14]] = [0, 1, 2, 3]; rank[[9, 10, 12, 15]] = [0, 1, 2, 3]
-                    loc = np.arange(R) - np.repeat(goff[:-1], ns)
-                    nrow = np.repeat(ns, ns)
-                    rng = np.random.default_rng(1)
-                    for u in range(7):
-                        hi = rng.integers(0, 1 << 30, R) % np.maximum(nrow // 4 - 1, 1)
-                        ell[:, u] = (hi * 4 + ((rank[loc & 15] + u) & 3)).astype(np.uint16)
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
         self.nnz_max = int(nnzs.max()) if B else 0
