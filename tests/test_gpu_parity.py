@@ -1097,8 +1097,8 @@ def _slab_of(W1: np.ndarray) -> np.ndarray:
     return pad.reshape(N, -1, 16).transpose(1, 0, 2).copy()
 
 
-@pytest.mark.parametrize("hidden", [500, 72])      # 72 = 4.5 slabs: a partly padded last slab
-def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden):
+@pytest.mark.parametrize("hidden,gps", [(500, 2), (72, 2), (72, 1)])      # 72 = 4.5 slabs: a partly padded last slab;
+def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden, gps):   # 1 graph per step: Adam inside the backward
     """The slab copy of conv1.weight (gmc_model.W1_slab): gmc_w1_slab_f32 lays it out as documented; a trainer
     whose fused forward reads it and whose Adam sweep keeps it current ends up with BIT-identical parameters,
     losses and copy (the copy changes where the W1 tile is fetched from, not what is computed) - on one GPU
@@ -1121,7 +1121,7 @@ def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden):
             T, cfg, net, embed, opt, params = model_and_params(pkg, hidden, seed=9)
             eng = net.engine()
             eng.slab_enabled = slab and eng.slab_enabled
-            tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=2, engine=WithoutFusedStep(eng) if dp_sequence else eng)
+            tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=gps, engine=WithoutFusedStep(eng) if dp_sequence else eng)
             if dp_sequence:
                 tr.dp = True                          # the all-reduce itself is a no-op without a process group
             losses = [tr.epoch(ds) for _ in range(3)]
