@@ -310,7 +310,9 @@ def main():
         "launch": ("hipGraph replay" if trainer._graph is not None else
                    "hipGraphs around the eager all-reduce" if trainer._dp_graph is not None else
                    "eager launches queued behind the previous step's backward (losses stored into pinned host memory)"
-                   if getattr(trainer, "_loss_host_dev", None) and not dp else "eager"),
+                   if getattr(trainer, "_loss_host_dev", None) and not dp else
+                   "eager launches around the all-reduce (loss published to pinned host memory ahead of Adam)"
+                   if dp and getattr(trainer, "_step_host_dev", None) else "eager"),
         "ms_per_step_eager_probed": eager_ms,
         "kernels_ms": {k: round(v, 5) for k, v in sorted(kmean.items())},
         "steady_state_note": "the first ~30 steps of a fresh process run ~9 % slower (clock ramp); the timed steps are the "

@@ -1057,7 +1057,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(pkg):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
-    assert d["config"]["parallelism"] == "dp2" and d["launch"] == "hipGraphs around the eager all-reduce"
+    assert d["config"]["parallelism"] == "dp2" and d["launch"].startswith("eager launches around the all-reduce")
     assert d["strong_scaling"]["graphs_per_gpu"] == 6 and d["strong_scaling"]["value"] > 0
     assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
     assert "cpu_baseline" not in d
@@ -1084,7 +1084,7 @@ def test_bench_single_rank_over_rccl(pkg):
         lines[tag] = json.loads(line)
     d, s = lines["rccl"], lines["single"]
     assert d["backend"] == "nccl" and d["n_gpus"] == 1 and d["config"]["parallelism"] == "dp1"
-    assert d["launch"] == "hipGraphs around the eager all-reduce" and s["launch"].startswith("eager launches queued")
+    assert d["launch"].startswith("eager launches around the all-reduce") and s["launch"].startswith("eager launches queued")
     assert d["allreduce_ms_per_step"] > 0 and d["value"] > 0
     assert d["last_loss"] == s["last_loss"]          # same six graphs, same six steps, integer-valued loss
 
@@ -1098,13 +1098,14 @@ def _slab_of(W1: np.ndarray) -> np.ndarray:
 
 
 @pytest.mark.parametrize("hidden,gps", [(500, 2), (72, 2), (72, 1)])      # 72 = 4.5 slabs: a partly padded last slab;
-def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden, gps):   # 1 graph per step: Adam inside the backward
+def test_w1_slab_copy_layout_and_bitwise_identical_training(pkg, hidden, gps, monkeypatch):
     """The slab copy of conv1.weight (gmc_model.W1_slab): gmc_w1_slab_f32 lays it out as documented; a trainer
     whose fused forward reads it and whose Adam sweep keeps it current ends up with BIT-identical parameters,
     losses and copy (the copy changes where the W1 tile is fetched from, not what is computed) - on one GPU
     (whole-step hipGraph) and on the data-parallel step sequence (graphs either side of the all-reduce)."""
     specs = [(1000, 7, 61), (700, 7, 62), (1000, 7, 63), (520, 6, 64)]
     ds = util.product_dataset(specs)
+    monkeypatch.setenv("GCN_MAXCUT_DP_GRAPHS", "1")   # the data-parallel sequence replayed from hipGraphs (opt-in)
 
     class WithoutFusedStep:           # an engine that offers only what the N > 1 branch uses
         def __init__(self, eng):
