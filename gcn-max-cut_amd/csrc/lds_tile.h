@@ -6,9 +6,10 @@
 #include <stdlib.h>
 
 
-// Diagnostic build only (-DGMC_STAMP, `make stamp`): wave 0 of every workgroup accumulates the
-// shader-clock cycles it spends in each phase of the fused kernels' tile loop into g_stamps
-// (never read by any kernel); gmc_debug_read_stamps copies them out.  The production library
+// Diagnostic build only (-DGMC_STAMP, `make stamp`): EVERY wave of the first 256 workgroups accumulates the
+// shader-clock cycles it spends in each phase of the fused kernels' tile loop into g_stamps[(block, wave)][12]
+// (never read by any kernel); gmc_debug_read_stamps copies them out.  (Wave 0 alone gives a skewed picture: the
+// LDS serves the oldest wave first, so it reaches every barrier early and waits the longest.)  The production library
 // contains none of this.
 #ifdef GMC_STAMP
 static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per translation unit (no device linking)
@@ -23,15 +24,15 @@ static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per trans
     } while (0)
 #define STAMP_FLUSH                                                                    \
     do {                                                                               \
-        if (threadIdx.x == 0 && blockIdx.x < 4096)                                     \
-            for (int i = 0; i < 12; ++i) g_stamps[blockIdx.x * 16 + i] = st_acc[i];    \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && threadIdx.x < 1024)         \
+            for (int i = 0; i < 12; ++i) g_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + i] = st_acc[i]; \
     } while (0)
 // wall-clock marks (s_memrealtime: one 100 MHz counter for the whole chip) in slots 12..15 of the workgroup:
 // kernel entry, tile loop start, tile loop end, kernel exit - where a launch's fixed time goes
 #define MARK(i)                                                                                  \
     do {                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                       \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 16 + 12 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+        if (threadIdx.x == 0 && blockIdx.x < 256) g_stamps[blockIdx.x * 256 + 12 + (i)] = __builtin_amdgcn_s_memrealtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                       \
     } while (0)
 #else

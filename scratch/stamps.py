@@ -11,19 +11,32 @@ eng = net.engine(); lib = pkg.hip.load()
 names = {"fwd": ["loop", "dma_wait", "barrier1", "gather1", "barrier2", "stores+dma", "gather2"],
          "bwd": ["loop", "transform+consts_dma", "barrierA", "gather1+consts_wait", "barrierB", "tile_dma_issue", "gather2", "tile_dma_wait", "-", "next_ids", "-"]}
 def read(nblk, which):
-    buf = (C.c_ulonglong * (nblk * 16))()
-    rc = getattr(lib, "gmc_debug_read_stamps_" + which)(buf, nblk * 16); assert rc == 0
-    return np.frombuffer(buf, dtype=np.uint64).reshape(nblk, 16).astype(np.float64)
+    # [block][wave][16]: slots 0..11 = phase cycles of that wave, slots 12..15 of wave 0 = wall-clock marks
+    buf = (C.c_ulonglong * (nblk * 256))()
+    rc = getattr(lib, "gmc_debug_read_stamps_" + which)(buf, nblk * 256); assert rc == 0
+    full = np.frombuffer(buf, dtype=np.uint64).reshape(nblk, 16, 16).astype(np.float64)
+    read.waves = full                      # every wave's phase cycles
+    return full[:, 0, :].copy()            # wave 0 (+ the marks), the shape the rest of this script expects
+def all_waves(label, names):
+    w = read.waves[:, :, :len(names)]      # [block][wave][phase]
+    tot = w.sum(2, keepdims=True)
+    share = 100 * w / tot
+    print(label, "share of cycles per phase, mean over ALL waves:", {k: round(float(share[:, :, i].mean()), 1) for i, k in enumerate(names)})
+    bar = [i for i, k in enumerate(names) if k.lower().startswith("barrier")]
+    bs = share[:, :, bar].sum(2)
+    print(label, "barrier share by wave (0 = oldest):", [round(float(bs[:, v].mean()), 1) for v in range(16)], "mean %.1f" % bs.mean())
 for _ in range(3): eng.train_fwd_bwd(batch)
 torch.cuda.synchronize()
 # forward only -> stamps of fwd1 (grid 1280)
 eng.forward(batch); torch.cuda.synchronize()
 a = read(256, 'fwd')
 tot = a[:, :12].sum(1).mean()
+all_waves("fwd1", names["fwd"])
 print("fwd1 cycles per WG %.0f" % tot, {k: round(100 * a[:, i].mean() / tot, 1) for i, k in enumerate(names["fwd"])}, "epilogue %.1f prologue %.1f" % (100 * a[:, 7].mean() / tot, 100 * a[:, 11].mean() / tot))
 eng.train_fwd_bwd(batch); torch.cuda.synchronize()
 b = read(256, 'bwd')
 tot = b[:, :11].sum(1).mean()
+all_waves("bwd1", names["bwd"])
 print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})
 
 def marks(x, label):
