@@ -31,7 +31,7 @@ The JSON line also carries
                   variant B = oracle/gcn_oracle.c (scalar C: CSR SpMM, fused
                   argmax / loss), 1 thread.
 
-Order of the regions inside one run: `sequential`, the per-kernel probe (30 untimed + K eager steps with HIP
+Order of the regions inside one run: `sequential`, the per-kernel probe (150 untimed + K eager steps with HIP
 events around every kernel), the one-kernel-per-operation leg, and LAST the headline: W untimed warmup steps,
 then exactly K timed steps between barrier + synchronize pairs.  A fresh process needs ~30 steps to reach the
 clocks the chip sustains; with the headline last its timed steps are sustained-clock steps at any K / W.
@@ -224,7 +224,8 @@ def main():
     eager_ms = None
     if not args.no_probe:
         trainer.allow_graph = False
-        for _ in range(30):   # the probe's own untimed steps (kernel set-up, clocks): its means feed `roofline_step`
+        for _ in range(150):  # the probe's own untimed steps (kernel set-up; ~40 ms of full load bring the chip to its
+                              # sustained clocks after the light reference-schedule region): its means feed `roofline_step`
             trainer.epoch(dataset)
         sync()
         te = time.perf_counter()
@@ -243,7 +244,7 @@ def main():
     if args.mode == "batched" and not args.no_probe:
         lib = pkg.hip.load()
         prev = lib.gmc_set_fuse(0)
-        for _ in range(2):
+        for _ in range(10):
             trainer.epoch(dataset)
         with pkg.hip.Probe(launches_per_step * args.steps) as p2:
             for _ in range(args.steps):
