@@ -168,12 +168,12 @@ def _dense_forward(net: "GCNSoftmax", g: GraphHandle, inputs: torch.Tensor) -> t
     eng = net.engine()
     lib, p = hip.load(), hip.ptr
     batch = GraphBatch([g], [None], eng.device)
-    v = eng.views()
+    v = eng.padded_views()   # (hidden dimension padded to a multiple of 4: pad columns are zeros)
     X = inputs.detach().to(eng.device, torch.float32)
     if X.shape != (g.n, eng.N):
         raise ValueError(f"features must be [{g.n}, {eng.N}], got {tuple(X.shape)}")
     T0 = ((X * batch.dinv[:, None]) @ v["conv1.weight"]).contiguous()
-    F_ = eng.F
+    F_ = eng.Fp
     H = torch.empty((g.n, F_), dtype=torch.float32, device=eng.device)
     Z0 = torch.empty((g.n, 3), dtype=torch.float32, device=eng.device)
     P = torch.empty((g.n, 3), dtype=torch.float32, device=eng.device)

@@ -55,25 +55,38 @@ struct Workspace {
 };
 
 bool dropout_on(const gmc_model *m) { return m->dropout_p > 0.f; }
+bool fuse_enabled();
+bool use_lds(const gmc_batch *b, const gmc_model *m);
 unsigned long long dropout_seed(const gmc_model *m) { return ((unsigned long long)m->dropout_seed_hi << 32) | m->dropout_seed_lo; }
 
-// GMC_SPMM_ALGO=rows|lds forces one SpMM implementation (A/B runs recorded under profiles/);
-// default: LDS-staged tiles whenever the largest graph fits a CU's LDS.
-bool use_lds(const gmc_batch *b) {
+// Fused layer kernels (default) vs the one-kernel-per-op sequence: gmc_set_fuse(0) selects the latter
+// (bench.py times the stand-alone SpMM kernel that way).  The shipped library reads no environment variables;
+// tuning builds (`make variant DEFS=-DGMC_TUNING`) also honour GMC_FUSE=0 and GMC_SPMM_ALGO=rows.
+int g_fuse = -1;
+bool fuse_enabled() {
+    if (g_fuse < 0) {
+        g_fuse = 1;
+#ifdef GMC_TUNING
+        const char *e = getenv("GMC_FUSE");
+        if (e && e[0] == '0') g_fuse = 0;
+#endif
+    }
+    return g_fuse != 0;
+}
+
+// LDS-staged tiles whenever the largest graph fits a CU's LDS.  A batch with overflow lists (rows of more than
+// ell_width neighbours) is served by the FUSED LDS kernels only: with the one-kernel-per-operation sequence
+// selected, or with dropout (which runs that sequence), it takes the row kernels.
+bool use_lds(const gmc_batch *b, const gmc_model *m) {
+#ifdef GMC_TUNING
     static const int forced = [] {
         const char *e = getenv("GMC_SPMM_ALGO");
         return !e ? 0 : (e[0] == 'r' ? 1 : 2);
     }();
     if (forced == 1) return false;
+#endif
+    if (b->ovf_ptr && (!fuse_enabled() || (m && m->dropout_p > 0.f))) return false;
     return gmc_lds_fits(b);
-}
-
-// Fused layer kernels (default) vs the one-kernel-per-op sequence; GMC_FUSE=0 or gmc_set_fuse(0)
-// selects the latter (bench.py times the stand-alone SpMM kernel that way).
-int g_fuse = -1;
-bool fuse_enabled() {
-    if (g_fuse < 0) { const char *e = getenv("GMC_FUSE"); g_fuse = (e && e[0] == '0') ? 0 : 1; }
-    return g_fuse != 0;
 }
 
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -88,7 +101,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
     };
     const size_t R = (size_t)b->R, F = (size_t)m->F;
     w.ld = (long)((F + 31) / 32 * 32);
-    w.fs = use_lds(b) ? gmc_lds_slice_width(b) : 0;
+    w.fs = use_lds(b, m) ? gmc_lds_slice_width(b) : 0;
     w.zparts = (w.fs && !dropout_on(m)) ? gmc_lds_groups(b, m->F) : 1;   // (dropout: Z0 comes from its own kernel)
     const size_t cols = w.fs ? (F + w.fs - 1) / w.fs * w.fs : (size_t)w.ld;
     w.T0 = take(R * cols);
@@ -100,7 +113,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
         if (w.fs && (size_t)gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, F)) > tiles) tiles = gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, F));
         w.part = take(tiles * F * 4);
         w.db2part = take((size_t)b->B * 3);
-        w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, use_lds(b)));
+        w.dw1part = take(gmc_dw1_scratch_floats(b, m->N, m->F, w.fs != 0));
         if (dropout_on(m)) w.W2s = take(F * 3);
     }
     w.bytes = off;
@@ -109,6 +122,7 @@ Workspace carve(const gmc_batch *b, const gmc_model *m, int training, void *base
 
 int check(const gmc_batch *b, const gmc_model *m) {
     if (!b || !m) return GMC_ERR_NULL;
+    if (b->abi != GMC_VERSION || m->abi != GMC_VERSION) return GMC_ERR_ABI;   // built against another header
     if (!b->goff || !b->rowptr || !b->gcol || !b->lcol || !b->dinv) return GMC_ERR_NULL;
     if (!m->W1 || !m->b1 || !m->W2 || !m->b2) return GMC_ERR_NULL;
     if (m->K != 3) return GMC_ERR_CLASSES;
@@ -275,7 +289,8 @@ extern "C" const char *gmc_error_string(int code) {
         case GMC_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
         case GMC_ERR_WORKSPACE: return "workspace too small";
         case GMC_ERR_GRAPH_SIZE: return "graph has fewer than 3 or more than GMC_MAX_GRAPH_NODES nodes";
-        case GMC_ERR_UNSUPPORTED: return "unsupported shape (hidden_dim must be a multiple of 4 and <= 1024)";
+        case GMC_ERR_UNSUPPORTED: return "unsupported shape (the leading dimension F must be a multiple of 4 and <= 1024)";
+        case GMC_ERR_ABI: return "gmc_batch.abi / gmc_model.abi differs from the library's GMC_VERSION: rebuild the caller against this include/gcnmaxcut.h";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown gmc error";
     }
 }
@@ -340,7 +355,7 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     if (!param || !grad || !mom || !var || !step_counter) return GMC_ERR_NULL;
     if (!gmc_aligned16(param) || !gmc_aligned16(mom) || !gmc_aligned16(var)) return GMC_ERR_ALIGN;
     const long nW1 = (long)N * F;
-    gmc_model model{N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3, 0.f, 0u, 0u, w1_slab};
+    gmc_model model{GMC_VERSION, N, F, 3, 0, param, param + nW1, param + nW1 + F, param + nW1 + F + (long)F * 3, 0.f, 0u, 0u, w1_slab};
     int rc = check(batch, &model);
     if (rc) return rc;
     if (!P || !workspace) return GMC_ERR_NULL;

@@ -143,7 +143,7 @@ __device__ __forceinline__ void dma_row_consts(const float *GY2, int r0, int n, 
 //   (Tried and dropped, measured same-box: pulling the H tile of graph g+2 into L2 with 4-byte LDS-DMA
 //   touches while the tile of g+1 streams in, so that the DMA runs at L2 latency - the kernel got 11 %
 //   SLOWER; the tile DMA's only shadow stays gather #2.)
-template <int FS, int ACC, bool HAS_VAL, int NS>
+template <int FS, int ACC, bool HAS_VAL, int NS, bool OVF>
 __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W = 8;
@@ -169,6 +169,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
+    constexpr bool ovf = OVF;   // some row of the batch has more than 8 neighbours: overflow lists (gmc_batch.ovf_*)
 
     uint4 idr[ACC];
     // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
@@ -227,6 +228,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
             float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
+            if (ovf && l < n) gmc::f4_add(u, gather_overflow<FS, false>(bufA, a.b, r0 + l, q));   // hub rows: their own extra blocks
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
         }
@@ -246,6 +248,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
             if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
             else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
+            if (ovf && lrow + k * kRowsPerPass < n) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, a.b, r0 + l, q));
             // the sum is needed HERE (its only user is the store after the graph loop: left alone the
             // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
             asm volatile("" : "+v"(acc[k]));
@@ -272,48 +275,66 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     MARK(3);
 }
 
-// ---- 16-slot tables (degree 9..16): neighbour table in LDS, three barriers per graph ----------------
-template <int FS, int W, int ACC, bool HAS_VAL>
+// ---- 16-slot tables (degree 9..16): neighbour table in LDS ------------------------------------------
+// LDS holds the two tiles and the 32-byte-per-row table, nothing else (n = 1000 fits: 2 x 64,256 + 32,000 B).
+// The row constants (GY2[r,:], dinv[r]) the transform needs are staged through the U tile's buffer, which is
+// idle between the end of gather #2 of graph g-1 and the start of gather #1 of graph g: a thread loads one
+// row's 16 B of graph g+1 into registers behind gather #2 and commits it with the table.
+//     transform(g) [own cells; row constants from bufB] -> S -> gather #1 (bufA -> bufB) -> S ->
+//     DMA(g+1) -> bufA, table / row constants(g+1) -> registers || gather #2 -> S -> commit -> S
+template <int FS, int W, int ACC, bool HAS_VAL, int NS, bool OVF>
 __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
     constexpr int kRowsPerPass = kThreads / Q;
     constexpr int NT = (ACC * kRowsPerPass * (W / 8) + kThreads - 1) / kThreads;
+    constexpr int RC = (ACC * kRowsPerPass + kThreads - 1) / kThreads;   // row-constant rows per thread
     int chunk, s;
     tile_of((int)blockIdx.x, a.chunks, a.slices, chunk, s);
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
     unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
-    float *gyl = reinterpret_cast<float *>(nb + (size_t)a.b.n_max * W);  // [n][4] = (GY2[r,:], dinv[r]) of the graph
+    float4 *gyl = reinterpret_cast<float4 *>(bufB);  // [n] x (GY2[r,:], dinv[r]): 16 n B <= the tile's 4 FS n B, below its zero rows
     float *red = bufB;  // cross-wave fold area, used after the graph loop
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
     const int f0 = s * FS + 4 * q;
     const bool col_on = f0 < a.F;
     const long slab = (long)s * a.b.R * FS;
+    constexpr bool ovf = OVF;   // some row of the batch has more than W neighbours: overflow lists (gmc_batch.ovf_*)
     ColState cs;
     col_state_init(cs, a.W2, f0, col_on);
     gmc::v4f acc[ACC];
     uint4 pt[NT];
+    float4 rc[RC];
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
 
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
-    auto fetch = [&](int r0, int n) {  // H tile -> bufA (DMA); neighbour table -> registers
+    auto fetch = [&](int r0, int n) {  // H tile -> bufA (DMA); neighbour table and row constants -> registers
         dma_tile<FS, ACC, true>(a.H + slab + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);   // H: read once
-        dma_row_consts(a.GY2, r0, n, gyl);
         const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int i = threadIdx.x + k * kThreads;
             pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
         }
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            rc[k] = reinterpret_cast<const float4 *>(a.GY2)[r0 + min(i, n - 1)];
+        }
     };
-    auto commit_table = [&](int n) {  // (and the zero rows the padding entries point at)
+    auto commit = [&](int n) {  // table, row constants (and the zero rows the padding entries point at)
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int i = threadIdx.x + k * kThreads;
             if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
+        }
+#pragma unroll
+        for (int k = 0; k < RC; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            if (i < n) gyl[i] = rc[k];
         }
         if (threadIdx.x < kPadRows * FS) {
             bufA[n * FS + threadIdx.x] = 0.f;
@@ -323,28 +344,29 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     fetch(r0, n);
-    commit_table(n);
+    commit(n);
     dma_wait();
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
         const int r0n = r0 + n;                                        // == goff[g + 1]
         const int nn = g + 1 < g1 ? a.b.goff[g + 2] - r0n : n;         // next graph's size (used after gather 1)
         float dv[ACC];
-        // (1) H -> Gs in place + column partials (row constants from LDS: they came with the tile)
+        // (1) H -> Gs in place + column partials (row constants: staged in bufB with the table)
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
-            const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
+            const float4 rck = gyl[min(l, n - 1)];
             dv[k] = rck.w;
             transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck);
         }
-        __syncthreads();
+        __syncthreads();   // every Gs cell is written; nobody reads the row constants any more: bufB is the U tile now
         // (2) U tile = dinv o (A @ Gs)
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
-                float4 u = gather_row<FS, W, false>(bufA, nb, nullptr, l, q);
+                float4 u = gather_row<FS, W, false, NS>(bufA, nb, nullptr, l, q);
+                if (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, a.b, r0 + l, q));
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
@@ -357,13 +379,14 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
-                acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+                acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL, NS>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
+                if (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, a.b, r0 + l, q));
                 asm volatile("" : "+v"(acc[k]));
             }
         }
         dma_wait();
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
-        if (g + 1 < g1) commit_table(nn);
+        if (g + 1 < g1) commit(nn);
         __syncthreads();
         r0 = r0n; n = nn;
     }
@@ -381,25 +404,25 @@ template <int FS, int W>
 int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
+    if (acc > 8) return GMC_ERR_UNSUPPORTED;
     const int grid = a.slices * a.chunks;
     const bool hv = a.b.ell_vals != nullptr;
+    const int ns = ns_class(W, a.b.ell_slots, !hv);   // live slots: no row of the batch has more neighbours
+    const bool ov = a.b.ovf_ptr != nullptr;   // hub rows: every slot live, overflow lists walked
     if constexpr (W == 8) {
-        if (a.b.ell_slots == 7 && !hv) {  // no row of the batch has more than 7 neighbours: slot 7 is skipped
-            if (acc <= 4) return launch(bwd1_reg_kernel<FS, 4, false, 7>, grid, lds, st, a);
-            if (acc <= 8) return launch(bwd1_reg_kernel<FS, 8, false, 7>, grid, lds, st, a);
-            return GMC_ERR_UNSUPPORTED;
-        }
-        if (acc <= 4) return hv ? launch(bwd1_reg_kernel<FS, 4, true, 8>, grid, lds, st, a)
-                                : launch(bwd1_reg_kernel<FS, 4, false, 8>, grid, lds, st, a);
-        if (acc <= 8) return hv ? launch(bwd1_reg_kernel<FS, 8, true, 8>, grid, lds, st, a)
-                                : launch(bwd1_reg_kernel<FS, 8, false, 8>, grid, lds, st, a);
+#define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_reg_kernel<FS, 4, HV, NSK, OV>, grid, lds, st, a) \
+                                        : launch(bwd1_reg_kernel<FS, 8, HV, NSK, OV>, grid, lds, st, a))
+        if (ov) return hv ? GMC_BWD1(true, 8, true) : GMC_BWD1(false, 8, true);
+        return hv ? GMC_BWD1(true, 8, false) : ns == 7 ? GMC_BWD1(false, 7, false) : GMC_BWD1(false, 8, false);
+#undef GMC_BWD1
     } else {
-        if (acc <= 4) return hv ? launch(bwd1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
-                                : launch(bwd1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
-        if (acc <= 8) return hv ? launch(bwd1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
-                                : launch(bwd1_lds_kernel<FS, W, 8, false>, grid, lds, st, a);
+#define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_lds_kernel<FS, W, 4, HV, NSK, OV>, grid, lds, st, a) \
+                                        : launch(bwd1_lds_kernel<FS, W, 8, HV, NSK, OV>, grid, lds, st, a))
+        if (ov) return hv ? GMC_BWD1(true, 16, true) : GMC_BWD1(false, 16, true);
+        return hv ? GMC_BWD1(true, 16, false) : ns == 10 ? GMC_BWD1(false, 10, false) : ns == 12 ? GMC_BWD1(false, 12, false)
+                  : ns == 14 ? GMC_BWD1(false, 14, false) : GMC_BWD1(false, 16, false);
+#undef GMC_BWD1
     }
-    return GMC_ERR_UNSUPPORTED;
 }
 
 }  // namespace

@@ -104,6 +104,7 @@ extern "C" int gmc_decode_sample_f32(const gmc_batch *batch, const float *P, con
                                      gmc_stream_t stream) {
     if (!batch || !P || !uniforms || !uoff || !assign_all || !cut_all || !best_assign || !best_cut || !best_iter)
         return GMC_ERR_NULL;
+    if (batch->abi != GMC_VERSION) return GMC_ERR_ABI;
     if (!batch->goff || !batch->rowptr || !batch->lcol) return GMC_ERR_NULL;
     if (iters < 1 || batch->B < 0) return GMC_ERR_SHAPE;
     if (batch->B > 0 && (batch->n_max < 3 || batch->n_max > 65535)) return GMC_ERR_GRAPH_SIZE;

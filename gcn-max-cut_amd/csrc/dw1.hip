@@ -124,7 +124,11 @@ int gmc_dw1_chunks(int B, bool lds, int slices) {
     if (lds) {  // (slice, chunk) workgroups: one round of one workgroup per CU (256 / slices chunks, at
                 // most 16 so that the [chunks][n_max][F] partials stay small); fewer, longer workgroups
                 // amortise their set-up and leave the fold fewer partials to read
-        static const int env = getenv("GMC_DW1_CHUNKS") ? atoi(getenv("GMC_DW1_CHUNKS")) : 0;  // tuning runs only
+#ifdef GMC_TUNING   // tuning builds only: the shipped library reads no environment
+        static const int env = getenv("GMC_DW1_CHUNKS") ? atoi(getenv("GMC_DW1_CHUNKS")) : 0;
+#else
+        constexpr int env = 0;
+#endif
         int cap = slices > 0 ? (256 + slices - 1) / slices : 8;
         if (cap > 16) cap = 16;
         if (env > 0) cap = env;

@@ -32,7 +32,8 @@ void arrange_quad(const int rows[4], int nrows_valid, const int32_t *rowptr, con
     for (int i = 0; i < 4; ++i) {
         if (rows[i] < 0) continue;
         const int r = r0 + rows[i];
-        for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+        const int end = std::min(rowptr[r + 1], rowptr[r] + W);  // the first W neighbours: the rest are overflow entries
+        for (int e = rowptr[r]; e < end; ++e) {
             byc[i][lcol[e] & 3].push_back({lcol[e], vals ? vals[e] : 1.0f});
             ++rem[i];
         }
@@ -123,13 +124,13 @@ void arrange_quad(const int rows[4], int nrows_valid, const int32_t *rowptr, con
 
 }  // namespace
 
-// All pointers are HOST pointers.  ell: [R][W] (W = 8 or 16, >= max degree), ell_vals: [R][W] or NULL.
+// All pointers are HOST pointers.  ell: [R][W] (W = 8 or 16; a longer row's first W neighbours), ell_vals: [R][W] or NULL.
 // Padding entries are n_g .. n_g+3 (four all-zero tile rows, one per bank quarter).
 extern "C" int gmc_ell_slots_for(int32_t R, const int32_t *rowptr, int32_t W) {
-    if (W != 8 || !rowptr) return W;
+    if ((W != 8 && W != 16) || !rowptr) return W;
     int top = 0;
-    for (int r = 0; r < R; ++r) top = std::max(top, rowptr[r + 1] - rowptr[r]);
-    return top <= 7 ? 7 : 8;
+    for (int r = 0; r < R; ++r) top = std::max(top, std::min(rowptr[r + 1] - rowptr[r], W));
+    return std::max(top, W == 8 ? 7 : 9);   // the kernels' smallest specialisations
 }
 
 extern "C" int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_t *rowptr, const int32_t *lcol,
@@ -140,8 +141,6 @@ extern "C" int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_
     for (int g = 0; g < B; ++g) {
         const int r0 = goff[g], n = goff[g + 1] - r0;
         if (n + 4 > 65535) return GMC_ERR_GRAPH_SIZE;
-        for (int r = r0; r < r0 + n; ++r)
-            if (rowptr[r + 1] - rowptr[r] > W) return GMC_ERR_SHAPE;
         for (int blk = 0; blk < n; blk += 16) {
             for (int qd = 0; qd < 4; ++qd) {
                 int rows[4], valid = 0;

@@ -19,7 +19,7 @@ namespace {
 // H = relu(dinv o (A @ T0) + b1) (:80-81) from B, with the layer-2 feature transform
 // (H o dinv) @ W2 (:83) accumulated in registers.  T0 never exists in HBM: the forward of layer 1
 // writes H once and reads only W1 (from L2) and the neighbour table.
-template <int FS, int W, int ACC, bool HAS_VAL, int NS>
+template <int FS, int W, int ACC, bool HAS_VAL, int NS, bool OVF>
 __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     STAMP_DECL;
     MARK(0);
@@ -41,11 +41,23 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
     const int TF = (int)tile_floats(a.b.n_max, FS);
     float *bufA = lds, *bufB = lds + TF;
     unsigned short *nb = reinterpret_cast<unsigned short *>(lds + 2 * TF);
-    // column constants of every slice, once per workgroup: [slices * FS] x (W2[c,0..2], b1[c])
+    // column constants (W2[c,0..2], b1[c]).  8-slot tables: those of every slice, once per workgroup
+    // [slices * FS].  16-slot tables (the table takes the room): two slices' worth [2][FS], slice s+1 loaded
+    // by the first FS threads while slice s is gathered (CSL)
+    constexpr bool CSL = W == 16;
     float4 *cst = reinterpret_cast<float4 *>(nb + (size_t)a.b.n_max * W);
     const int q = threadIdx.x % Q, lrow = threadIdx.x / Q;
+    constexpr bool ovf = OVF;   // some row of the batch has more than W neighbours: overflow lists (gmc_batch.ovf_*)
+    auto col_consts = [&](int cc) {   // (W2[cc,0..2], b1[cc]); zeros for pad columns
+        float4 c = gmc::f4_zero();
+        if (cc < a.F) {
+            if (a.W2) { c.x = a.W2[(long)cc * 3]; c.y = a.W2[(long)cc * 3 + 1]; c.z = a.W2[(long)cc * 3 + 2]; }
+            if (a.bias) c.w = a.bias[cc];
+        }
+        return c;
+    };
 
-    {   // (slices * FS <= 1024 = kThreads: one column per thread; pad columns hold zeros)
+    if (!CSL) {   // (slices * FS <= 1024 = kThreads: one column per thread; pad columns hold zeros)
         const int cc = threadIdx.x;
         const bool c_on = cc < a.slices * FS;
         float4 c = gmc::f4_zero();
@@ -77,6 +89,8 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
         dma(s_lo);
+        float4 cn = gmc::f4_zero();   // CSL: constants of my column of the NEXT slice (threads < FS), in flight
+        if (CSL && threadIdx.x < FS) cn = col_consts(s_lo * FS + (int)threadIdx.x);
         float sc[ACC];
 #pragma unroll
         for (int k = 0; k < ACC; ++k) sc[k] = a.scale[r0 + min(lrow + k * kRowsPerPass, n - 1)];
@@ -126,11 +140,17 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
             for (int k = 0; k < ACC; ++k) { z01[k] = gmc::splat2(0.f); z2[k] = 0.f; }
         };
         dma_wait();  // table / first tile
+        if (CSL && threadIdx.x < FS) cst[(s_lo & 1) * FS + threadIdx.x] = cn;   // (published by barrier 1 of the first slice)
         STAMP(11);  // prologue
         for (int s = s_lo; s < s_hi; ++s) {
             STAMP(0);  // loop overhead / previous tail
             // the W1 tile of slice s has landed once at most the ACC stores issued after its DMA are left
-            if (s > s_lo && !ABL(1) && !ABL(2)) vm_wait<ACC>();
+            if (s > s_lo && !ABL(1) && !ABL(2)) {
+                vm_wait<ACC>();
+                // (CSL: the constants' loads are older than the stores as well; gather #2 of slice s-2, the last
+                // reader of this half of the buffer, ended before barrier 1 of slice s-1)
+                if (CSL && threadIdx.x < FS) cst[(s & 1) * FS + threadIdx.x] = cn;
+            }
             STAMP(1);  // DMA wait
             loop_barrier();  // ... for every wave; readers of the previous T0 tile are done
             STAMP(2);  // barrier 1
@@ -146,6 +166,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int lc = min(l, n - 1);
                     float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
                                       : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                    if (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, a.b, r0 + lc, q));
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -155,6 +176,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int l = lrow + k * kRowsPerPass;
                     if (l < n) {
                         float4 t = gather_row<FS, W, HAS_VAL, NS>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
+                        if (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, a.b, r0 + l, q));
                         t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                         reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
                     }
@@ -164,13 +186,16 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
             loop_barrier();
             STAMP(4);  // barrier 2
             if (s > s_lo && s % per == 0) flush(s / per - 1);  // the group that ended with slice s-1
-            if (s + 1 < s_hi && !ABL(1)) dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+            if (s + 1 < s_hi && !ABL(1)) {
+                dma(s + 1);  // buffer A is free: the next W1 tile streams in during gather #2
+                if (CSL && threadIdx.x < FS) cn = col_consts((s + 1) * FS + (int)threadIdx.x);
+            }
             STAMP(5);  // DMA issue
             // gather #2: H rows + fused W2; every thread issues exactly ACC stores (rows past n repeat
             // row n-1: same value to the same address) so that the vm_wait above counts exactly
             // my 4 columns' constants (indexed by absolute column): W2 rows as (w0,w1) pairs + w2, bias pairs
-            const float4 c0 = cst[s * FS + 4 * q], c1 = cst[s * FS + 4 * q + 1], c2 = cst[s * FS + 4 * q + 2],
-                         c3 = cst[s * FS + 4 * q + 3];
+            const int cb = (CSL ? (s & 1) : s) * FS + 4 * q;
+            const float4 c0 = cst[cb], c1 = cst[cb + 1], c2 = cst[cb + 2], c3 = cst[cb + 3];
             const gmc::v2f w01[4] = {{c0.x, c0.y}, {c1.x, c1.y}, {c2.x, c2.y}, {c3.x, c3.y}};
             const float w2c[4] = {c0.z, c1.z, c2.z, c3.z};
             const gmc::v2f blo = {c0.w, c1.w}, bhi = {c2.w, c3.w};
@@ -202,9 +227,13 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                    emit(k, ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q));
+                    gmc::v4f h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
+                    if (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, a.b, r0 + l, q));
+                    emit(k, h);
                 } else {
-                    emit(k, gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q)));
+                    gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
+                    if (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, a.b, r0 + l, q));
+                    emit(k, h);
                 }
             }
             STAMP(6);  // gather 2
@@ -221,20 +250,18 @@ template <int FS, int W>
 int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
     constexpr int rows_per_pass = kThreads / (FS / 4);
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
-    // 7 live slots (no row of the batch has more than 7 neighbours): unit-weight kernels skip slot 7
-    const bool s7 = W == 8 && a.b.ell_slots == 7 && !a.use_vals;
-    if constexpr (W == 8) {
-        if (s7) {
-            if (acc <= 4) return launch(fwd1_lds_kernel<FS, W, 4, false, 7>, grid, lds, st, a);
-            if (acc <= 8) return launch(fwd1_lds_kernel<FS, W, 8, false, 7>, grid, lds, st, a);
-            return GMC_ERR_UNSUPPORTED;
-        }
-    }
-    if (acc <= 4) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 4, true, 8>, grid, lds, st, a)
-                                    : launch(fwd1_lds_kernel<FS, W, 4, false, 8>, grid, lds, st, a);
-    if (acc <= 8) return a.use_vals ? launch(fwd1_lds_kernel<FS, W, 8, true, 8>, grid, lds, st, a)
-                                    : launch(fwd1_lds_kernel<FS, W, 8, false, 8>, grid, lds, st, a);
-    return GMC_ERR_UNSUPPORTED;
+    if (acc > 8) return GMC_ERR_UNSUPPORTED;
+    // live slots (no row of the batch has more neighbours): unit-weight kernels skip the others
+    const int ns = ns_class(W, a.b.ell_slots, !a.use_vals);
+#define GMC_FWD1(AC, HV, NSK, OV) launch(fwd1_lds_kernel<FS, W, AC, HV, NSK, OV>, grid, lds, st, a)
+#define GMC_FWD1_ACC(HV, NSK, OV) (acc <= 4 ? GMC_FWD1(4, HV, NSK, OV) : GMC_FWD1(8, HV, NSK, OV))
+    if (a.b.ovf_ptr) return a.use_vals ? GMC_FWD1_ACC(true, W, true) : GMC_FWD1_ACC(false, W, true);   // hub rows: every slot live
+    if (a.use_vals) return GMC_FWD1_ACC(true, W, false);
+    if constexpr (W == 8) return ns == 7 ? GMC_FWD1_ACC(false, 7, false) : GMC_FWD1_ACC(false, 8, false);
+    else return ns == 10 ? GMC_FWD1_ACC(false, 10, false) : ns == 12 ? GMC_FWD1_ACC(false, 12, false)
+              : ns == 14 ? GMC_FWD1_ACC(false, 14, false) : GMC_FWD1_ACC(false, 16, false);
+#undef GMC_FWD1_ACC
+#undef GMC_FWD1
 }
 
 }  // namespace
@@ -248,8 +275,10 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
     const int slices = (F + fs - 1) / fs, groups = gmc_lds_groups(b, F);
-    // the column constants of every slice sit in LDS: 16 B per (padded) column
-    if ((size_t)slices * fs > (size_t)kThreads || (size_t)16 * slices * fs > lds_consts(b->n_max, fs)) return GMC_ERR_UNSUPPORTED;
+    // 8-slot tables: the column constants of every slice sit in LDS, 16 B per (padded) column (16-slot tables load
+    // them slice by slice)
+    if (b->ell_width == 8 && ((size_t)slices * fs > (size_t)kThreads || (size_t)16 * slices * fs > lds_consts(b->n_max, fs, 8)))
+        return GMC_ERR_UNSUPPORTED;
     // contiguous ranges of (graph, group) items, one persistent workgroup per CU when there are enough
     const int total = b->B * groups, cus = device_cus();
     const int ipw = (total + cus - 1) / cus, grid = (total + ipw - 1) / ipw;

@@ -247,7 +247,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_bwd_kernel(HeadBwdArgs a) {
 }
 
 int check_batch(const gmc_batch *b) {
-    if (!b || !b->goff || !b->rowptr || !b->gcol || !b->lcol || !b->dinv) return GMC_ERR_NULL;
+    if (!b) return GMC_ERR_NULL;
+    if (b->abi != GMC_VERSION) return GMC_ERR_ABI;
+    if (!b->goff || !b->rowptr || !b->gcol || !b->lcol || !b->dinv) return GMC_ERR_NULL;
     if (b->B < 0 || b->R < 0 || b->nnz < 0) return GMC_ERR_SHAPE;
     if (b->B > 0 && (b->n_max < 3 || b->n_max > GMC_MAX_GRAPH_NODES)) return GMC_ERR_GRAPH_SIZE;
     return GMC_OK;
@@ -277,7 +279,8 @@ int gmc_head_launch(const gmc_batch *batch, const float *Z0, int32_t z_parts, co
     if (batch->B == 0) return GMC_OK;
     HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, tick};
     const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
-    const bool ell = batch->ell != nullptr && batch->ell_width > 0;
+    // (rows with overflow lists: the CSR walk covers every neighbour)
+    const bool ell = batch->ell != nullptr && batch->ell_width > 0 && !batch->ovf_ptr;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(ell ? reinterpret_cast<const void *>(head_kernel<true>)
                                                : reinterpret_cast<const void *>(head_kernel<false>),

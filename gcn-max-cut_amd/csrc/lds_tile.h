@@ -113,18 +113,25 @@ __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
 constexpr int kPadRows = 4;
 __host__ __device__ inline size_t tile_floats(int n_max, int FS) { return (size_t)(n_max + kPadRows) * FS; }
 constexpr int kMaxSlicesPerWg = 8;
-// third LDS region (after the two tiles and the table): the larger of
+// third LDS region (after the two tiles and the table):
+//   8-slot tables - the larger of
 //   - the column constants (bias, W2 rows): 16 B per column - every slice of up to 1024 columns for
 //     the persistent fused forward, kMaxSlicesPerWg slices for the SpMM (8 * FS * 16 B <= that);
-//   - the per-row constants (GY2[r,:], dinv[r]) of the graph in flight in bwd1: 16 B per row
+//   - the per-row constants (GY2[r,:], dinv[r]) of the graph in flight in bwd1_reg: 16 B per row (its second
+//     copy of them sits in the table region: that kernel keeps the neighbour ids in registers);
+//   16-slot tables (the table is twice as large: 32 B per row) - only the column constants of the slices in
+//   flight: kMaxSlicesPerWg slices for the SpMM; two slices (double-buffered, loaded slice by slice) for the
+//   fused forward; the fused backward stages its row constants through the U tile's buffer, which is idle
+//   while they are needed.  That is what lets n = 1000 graphs of degree 9..16 stay on the LDS path:
+//   2 x 64,256 + 32,000 + 2,048 = 162,560 B of the 163,840.
 // (bwd1's cross-wave fold area of 256 * FS B re-uses a tile buffer after its graph loop).
-__host__ __device__ inline size_t lds_consts(int n_max, int FS) {
-    (void)FS;
+__host__ __device__ inline size_t lds_consts(int n_max, int FS, int W) {
+    if (W == 16) return (size_t)16 * kMaxSlicesPerWg * FS;
     const size_t cols = (size_t)16 * 1024, rows = (size_t)16 * (n_max + kPadRows);
     return cols > rows ? cols : rows;
 }
 size_t lds_bytes(int n_max, int W, int FS) {
-    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + lds_consts(n_max, FS);
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * W * 2 + lds_consts(n_max, FS, W);
 }
 
 // Asynchronous tile load (LDS-DMA, global_load_lds_dwordx4): thread t fetches float4
@@ -192,12 +199,13 @@ __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, boo
 // of the dword) instead of the unpack + shift-add pair the compiler emits: the gathers spend about
 // as many SIMD cycles on address arithmetic and adds as LDS cycles on the reads.
 //
-// NS = neighbour slots in use (8, or 7): for a batch whose largest degree is <= 7 - d = 7 regular graphs,
-// the headline workload - gmc_ell_arrange_host keeps slot 7 of every row for padding (gmc_batch.ell_slots
-// == 7) and the gathers neither read that row of zeros nor add it: 1/8 fewer LDS reads and packed adds in
-// all four gathers of a training step (-5 % on both fused kernels).
+// NS = neighbour slots in use (1..8 of this block of eight): for a batch whose largest degree is <= 7 - d = 7
+// regular graphs, the headline workload - gmc_ell_arrange_host keeps slot 7 of every row for padding
+// (gmc_batch.ell_slots == 7) and the gathers neither read that row of zeros nor add it: 1/8 fewer LDS reads and
+// packed adds in all four gathers of a training step.  16-slot tables likewise: d = 12 reads 8 + 4 slots.
 template <int NS = 8>
 __device__ __forceinline__ void read8(const float *tile, int q, unsigned row_bytes, const uint4 ids, float4 (&x)[8]) {
+    static_assert(NS >= 1 && NS <= 8, "slots of one block of eight");
     typedef float v4f __attribute__((ext_vector_type(4)));
     using lds_f4 = __attribute__((address_space(3))) const v4f;
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
@@ -205,6 +213,7 @@ __device__ __forceinline__ void read8(const float *tile, int q, unsigned row_byt
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         unsigned lo, hi;
+        if (2 * j >= NS) break;
         asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(lo) : "v"(pk[j]), "s"(row_bytes), "v"(base));
         const v4f a = *(lds_f4 *)(size_t)lo;
         x[2 * j] = make_float4(a.x, a.y, a.z, a.w);
@@ -216,33 +225,70 @@ __device__ __forceinline__ void read8(const float *tile, int q, unsigned row_byt
     }
 }
 
-// sum over the row's W neighbour slots (CSR order, padding -> zero row) from the LDS tile
-template <int FS, int W, bool HAS_VAL, int NS = 8>
+// sum over the row's first NS of W neighbour slots (slot order, padding -> zero row) from the LDS tile
+template <int FS, int W, bool HAS_VAL, int NS = W>
 __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
                                              int l, int q) {
-    static_assert(NS == 8 || (NS == 7 && W == 8), "7 slots: 8-slot tables only");
+    static_assert((W == 8 && (NS == 7 || NS == 8)) || (W == 16 && NS > 8 && NS <= 16), "live slots of the table");
     float4 acc = gmc::f4_zero();
 #pragma unroll
     for (int blk = 0; blk < W / 8; ++blk) {
+        constexpr int kFirst = NS < 8 ? NS : 8;
         const uint4 ids = *reinterpret_cast<const uint4 *>(nb + (long)l * W + blk * 8);
         float4 x[8];
-        read8<NS>(tile, q, FS * 4, ids, x);
+        if (blk == 0) read8<kFirst>(tile, q, FS * 4, ids, x);
+        else read8<(NS > 8 ? NS - 8 : 1)>(tile, q, FS * 4, ids, x);
+        const int live = blk == 0 ? kFirst : NS - 8;
         if (HAS_VAL) {  // weights come from HBM/L2: this (rare) variant waits on them per row
             const float4 w0 = *reinterpret_cast<const float4 *>(wrow + blk * 8);
             const float4 w1 = *reinterpret_cast<const float4 *>(wrow + blk * 8 + 4);
             const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-            for (int u = 0; u < NS; ++u) gmc::f4_fma(acc, w[u], x[u]);
+            for (int u = 0; u < 8; ++u)
+                if (u < live) gmc::f4_fma(acc, w[u], x[u]);
         } else if (blk == 0) {  // last read first: one wait per block (see gather_ids8)
-            acc = x[NS - 1];
+            acc = x[kFirst - 1];
 #pragma unroll
-            for (int u = NS - 2; u >= 0; --u) gmc::f4_add(acc, x[u]);
+            for (int u = kFirst - 2; u >= 0; --u) gmc::f4_add(acc, x[u]);
         } else {
 #pragma unroll
-            for (int u = 7; u >= 0; --u) gmc::f4_add(acc, x[u]);
+            for (int u = 7; u >= 0; --u)
+                if (u < live) gmc::f4_add(acc, x[u]);
         }
     }
     return acc;
+}
+
+// Overflow blocks of batch row r (gmc_batch.ovf_*: the neighbours beyond the table's W slots, eight ids per block,
+// padded with the zero row): summed block by block in order.  Only rows of hub degree have any, and only the thread
+// group that owns the row runs this loop, so a hub costs its own blocks (ids and weights come from L2 / L1).
+template <int FS, bool HAS_VAL>
+__device__ __forceinline__ float4 gather_overflow(const float *tile, const gmc_batch &b, int r, int q) {
+    float4 acc = gmc::f4_zero();
+    const int b0 = b.ovf_ptr[r], b1 = b.ovf_ptr[r + 1];
+    for (int blk = b0; blk < b1; ++blk) {
+        const uint4 ids = *reinterpret_cast<const uint4 *>(b.ovf_ids + 8l * blk);
+        float4 x[8];
+        read8<8>(tile, q, FS * 4, ids, x);
+        if (HAS_VAL) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(b.ovf_vals + 8l * blk);
+            const float4 w1 = *reinterpret_cast<const float4 *>(b.ovf_vals + 8l * blk + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
+        }
+    }
+    return acc;
+}
+
+// the kernels' NS specialisation for a table of W slots of which `slots` can hold a neighbour (gmc_batch.ell_slots)
+inline int ns_class(int W, int slots, bool unit_weights) {
+    if (!unit_weights || slots <= 0 || slots >= W) return W;
+    if (W == 8) return slots <= 7 ? 7 : 8;
+    return slots <= 10 ? 10 : slots <= 12 ? 12 : slots <= 14 ? 14 : 16;
 }
 
 // gather_row with the row's ids already fetched (W == 8: one uint4).  Callers issue the id read of
@@ -290,7 +336,11 @@ __device__ __forceinline__ gmc::v4f gather_ids8_pk(const float *tile, const uint
 // two tile buffers + table fit the CU's 160 KiB of LDS; 0 = does not fit (row kernels).
 int pick_fs(int n_max, int W) {
     if (n_max >= 65535 || (W != 8 && W != 16)) return 0;
-    static const int cap = getenv("GMC_LDS_MAX_FS") ? atoi(getenv("GMC_LDS_MAX_FS")) : 64;  // tuning runs only
+#ifdef GMC_TUNING   // tuning builds only (`make variant DEFS=-DGMC_TUNING`): the shipped library reads no environment
+    static const int cap = getenv("GMC_LDS_MAX_FS") ? atoi(getenv("GMC_LDS_MAX_FS")) : 64;
+#else
+    constexpr int cap = 64;
+#endif
     for (int fs = cap >= 16 ? cap : 64; fs >= 16; fs >>= 1)
         if (lds_bytes(n_max, W, fs) <= 160 * 1024) return fs;
     return 0;

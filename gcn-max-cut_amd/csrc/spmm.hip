@@ -241,7 +241,9 @@ struct Tune { int rpw = 0, unr = 0, nt = 0; };
 const Tune &tune() {
     static Tune t = [] {
         Tune v;
+#ifdef GMC_TUNING   // tuning builds only (`make variant DEFS=-DGMC_TUNING`): the shipped library reads no environment
         if (const char *e = getenv("GMC_SPMM_TUNE")) sscanf(e, "%d,%d,%d", &v.rpw, &v.unr, &v.nt);
+#endif
         return v;
     }();
     return t;

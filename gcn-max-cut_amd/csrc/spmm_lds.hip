@@ -38,7 +38,7 @@ namespace {
 //   LDS gather of slice s  ->  wait (loads s+1 done; stores s-1 long done)  ->
 //   write slice s+1 to the other LDS buffer  ->  barrier.
 // SHARED: the source is one table shared by every graph (W1 for the layer-1 feature transform)
-template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED, int NS = 8>
+template <int FS, int W, int ACC, bool EPI, bool HAS_VAL, bool SHARED, int NS = W>
 __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -196,7 +196,7 @@ struct Dw1TileArgs {
     int graphs_per_chunk;
 };
 
-template <int FS, int W, int ACC, bool HAS_VAL, int NS = 8>
+template <int FS, int W, int ACC, bool HAS_VAL, int NS = W>
 __global__ GMC_LDS_BOUNDS void dw1_lds_kernel(Dw1TileArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int Q = FS / 4;
@@ -287,16 +287,24 @@ int launch_spmm(const TileArgs &a, size_t lds, hipStream_t st) {
         return epi ? launch(spmm_lds_kernel<FS, W, AC, true, false, false>, grid, lds, st, a)                 \
                    : launch(spmm_lds_kernel<FS, W, AC, false, false, false>, grid, lds, st, a);               \
     } while (0)
+    // live slots (no row of the batch has more neighbours): the unit-weight aggregation skips the others
+    const int ns = ns_class(W, a.b.ell_slots, !a.use_vals && !a.shared_src);
+#define GMC_NS(NSK)                                                                                                    \
+    do {                                                                                                               \
+        if (acc <= 4) return epi ? launch(spmm_lds_kernel<FS, W, 4, true, false, false, NSK>, grid, lds, st, a)        \
+                                 : launch(spmm_lds_kernel<FS, W, 4, false, false, false, NSK>, grid, lds, st, a);      \
+        if (acc <= 8) return epi ? launch(spmm_lds_kernel<FS, W, 8, true, false, false, NSK>, grid, lds, st, a)        \
+                                 : launch(spmm_lds_kernel<FS, W, 8, false, false, false, NSK>, grid, lds, st, a);      \
+        return GMC_ERR_UNSUPPORTED;                                                                                    \
+    } while (0)
     if constexpr (W == 8) {
-        // 7 live slots (no row of the batch has more than 7 neighbours): the unit-weight aggregation skips slot 7
-        if (a.b.ell_slots == 7 && !a.use_vals && !a.shared_src) {
-            if (acc <= 4) return epi ? launch(spmm_lds_kernel<FS, W, 4, true, false, false, 7>, grid, lds, st, a)
-                                     : launch(spmm_lds_kernel<FS, W, 4, false, false, false, 7>, grid, lds, st, a);
-            if (acc <= 8) return epi ? launch(spmm_lds_kernel<FS, W, 8, true, false, false, 7>, grid, lds, st, a)
-                                     : launch(spmm_lds_kernel<FS, W, 8, false, false, false, 7>, grid, lds, st, a);
-            return GMC_ERR_UNSUPPORTED;
-        }
+        if (ns == 7) GMC_NS(7);
+    } else {
+        if (ns == 10) GMC_NS(10);
+        if (ns == 12) GMC_NS(12);
+        if (ns == 14) GMC_NS(14);
     }
+#undef GMC_NS
     if (acc <= 4) GMC_PICK(4);
     if (acc <= 8) GMC_PICK(8);
 #undef GMC_PICK
@@ -309,13 +317,21 @@ int launch_dw1(const Dw1TileArgs &a, size_t lds, hipStream_t st) {
     const int acc = (a.b.n_max + rows_per_pass - 1) / rows_per_pass;
     const int grid = a.slices * a.chunks;
     const bool hv = a.b.ell_vals != nullptr;
+    const int ns = ns_class(W, a.b.ell_slots, !hv);
+#define GMC_NS(NSK)                                                                        \
+    do {                                                                                   \
+        if (acc <= 4) return launch(dw1_lds_kernel<FS, W, 4, false, NSK>, grid, lds, st, a); \
+        if (acc <= 8) return launch(dw1_lds_kernel<FS, W, 8, false, NSK>, grid, lds, st, a); \
+        return GMC_ERR_UNSUPPORTED;                                                        \
+    } while (0)
     if constexpr (W == 8) {
-        if (a.b.ell_slots == 7 && !hv) {
-            if (acc <= 4) return launch(dw1_lds_kernel<FS, W, 4, false, 7>, grid, lds, st, a);
-            if (acc <= 8) return launch(dw1_lds_kernel<FS, W, 8, false, 7>, grid, lds, st, a);
-            return GMC_ERR_UNSUPPORTED;
-        }
+        if (ns == 7) GMC_NS(7);
+    } else {
+        if (ns == 10) GMC_NS(10);
+        if (ns == 12) GMC_NS(12);
+        if (ns == 14) GMC_NS(14);
     }
+#undef GMC_NS
     if (acc <= 4) return hv ? launch(dw1_lds_kernel<FS, W, 4, true>, grid, lds, st, a)
                             : launch(dw1_lds_kernel<FS, W, 4, false>, grid, lds, st, a);
     if (acc <= 8) return hv ? launch(dw1_lds_kernel<FS, W, 8, true>, grid, lds, st, a)
@@ -357,7 +373,11 @@ int gmc_lds_groups(const gmc_batch *b, int F) {
     const int fs = pick_fs(b->n_max, b->ell_width);
     if (!fs) return 0;
     const int slices = (F + fs - 1) / fs;
+#ifdef GMC_TUNING   // tuning builds only: the shipped library reads no environment
     static const int per_env = getenv("GMC_LDS_SLICES_PER_WG") ? atoi(getenv("GMC_LDS_SLICES_PER_WG")) : 0;
+#else
+    constexpr int per_env = 0;
+#endif
     int per = 4;
     if (per_env > 0) {
         per = per_env;
@@ -379,7 +399,7 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int x_slab
     if (!b || !X || !Y) return GMC_ERR_NULL;
     if (F % 4 || ldx % 4 || ldy % 4 || !gmc_aligned16(X) || !gmc_aligned16(Y))
         return GMC_ERR_ALIGN;
-    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    if (!gmc_lds_fits(b) || b->ovf_ptr) return GMC_ERR_UNSUPPORTED;   // (overflow lists: the fused kernels walk them)
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
     const long slab_ss = (long)b->R * fs;
@@ -403,11 +423,12 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int x_slab
 }
 
 // compute units of the current device (persistent kernels launch one workgroup per CU)
+static int g_cus_override = 0;
+// test hook (not in gcnmaxcut.h): pretend the device has `cus` compute units when the persistent forward deals its
+// items to workgroups, so that a small batch exercises long item ranges; 0 = the hardware's count
+extern "C" int gmc_debug_set_device_cus(int cus) { const int prev = g_cus_override; g_cus_override = cus > 0 ? cus : 0; return prev; }
 int device_cus(bool allow_override) {
-    if (const char *e = allow_override ? getenv("GMC_DEVICE_CUS") : nullptr) {  // tests: force long item ranges
-        const int v = atoi(e);
-        if (v > 0) return v;
-    }
+    if (allow_override && g_cus_override > 0) return g_cus_override;
     static int cus = 0;
     if (!cus) {
         int dev = 0, n = 0;
@@ -422,7 +443,7 @@ int device_cus(bool allow_override) {
 // dW1 partials: out[chunk][v][:] = sum_{g in chunk} sum_e vals[e] * U[g][nbr(e), :], v < n_max
 int gmc_dw1_lds_launch(const gmc_batch *b, const float *U, long ldu, int u_slab, float *out, int F, int chunks,
                        int graphs_per_chunk, hipStream_t st) {
-    if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    if (!gmc_lds_fits(b) || b->ovf_ptr) return GMC_ERR_UNSUPPORTED;
     const int fs = pick_fs(b->n_max, b->ell_width);
     Dw1TileArgs a{*b, U, u_slab ? fs : ldu, u_slab ? (long)b->R * fs : fs, out, F, (F + fs - 1) / fs, chunks,
                   graphs_per_chunk};

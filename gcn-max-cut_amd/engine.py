@@ -37,10 +37,15 @@ class FusedEngine:
         if K != 3:
             raise ValueError("number_classes must be 3: the terminal override is 3-wide "
                              "(TrainingNeural.py:91-93)")
-        if F % 4 or F > 1024:
-            raise ValueError("hidden_dim must be a multiple of 4 and <= 1024 on this path")
+        if F < 1 or F > 1024:
+            raise ValueError("hidden_dim must be in 1..1024 on this path")
         self.N, self.F, self.K = N, F, K
-        self.offs, self.count = flat_layout(N, F, K)
+        # Any hidden_dim (TrainingNeural.py:42,66-67 accept any int; n_nodes=50 gives 25): the kernels work on 16-byte
+        # column groups, so the flat buffer carries the hidden dimension padded to a multiple of 4 (Fp).  Pad columns of
+        # W1 / entries of b1 / rows of W2 are 0 and stay 0 (their activations are relu(0), every gradient entry is an
+        # exact 0, Adam of 0 is 0); the module's parameters and state_dict keep the logical shapes as views [:, :F].
+        self.Fp = (F + 3) // 4 * 4
+        self.offs, self.count = flat_layout(N, self.Fp, K)
         # + 4 floats of tail: slot `count` carries the summed loss through the all-reduce
         self.flat = torch.zeros(self.count + 4, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros_like(self.flat)
@@ -61,14 +66,22 @@ class FusedEngine:
 
     # ---- parameters
     def views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """The four tensors in the reference's (logical) shapes: views of ``buf`` (for hidden_dim % 4 != 0
+        ``conv1.weight`` is a strided view of the padded rows)."""
+        p, F = self.padded_views(buf), self.F
+        return {"conv1.weight": p["conv1.weight"][:, :F], "conv1.bias": p["conv1.bias"][:F],
+                "conv2.weight": p["conv2.weight"][:F], "conv2.bias": p["conv2.bias"]}
+
+    def padded_views(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """The same four tensors as the kernels see them: hidden dimension padded to Fp, contiguous."""
         buf = self.flat if buf is None else buf
-        o, N, F, K = self.offs, self.N, self.F, self.K
+        o, N, F, K = self.offs, self.N, self.Fp, self.K
         return {"conv1.weight": buf[o[0]:o[1]].view(N, F), "conv1.bias": buf[o[1]:o[2]],
                 "conv2.weight": buf[o[2]:o[3]].view(F, K), "conv2.bias": buf[o[3]:o[4]]}
 
     def _refresh_model(self) -> None:
-        v = self.views()
-        self._model = hip.GmcModel(N=self.N, F=self.F, K=self.K, flags=hip.MODEL_GRAD_TAIL,
+        v = self.padded_views()
+        self._model = hip.GmcModel(N=self.N, F=self.Fp, K=self.K, flags=hip.MODEL_GRAD_TAIL,
                                    W1=hip.ptr(v["conv1.weight"]), b1=hip.ptr(v["conv1.bias"]),
                                    W2=hip.ptr(v["conv2.weight"]), b2=hip.ptr(v["conv2.bias"]))
 
@@ -89,11 +102,11 @@ class FusedEngine:
             return 0
         sig = self._param_signature()
         if self.w1_slab is None:
-            self.w1_slab = torch.empty(int(self.lib.gmc_w1_slab_floats(self.N, self.F)), dtype=torch.float32,
+            self.w1_slab = torch.empty(int(self.lib.gmc_w1_slab_floats(self.N, self.Fp)), dtype=torch.float32,
                                        device=self.device)
             self._slab_sig = None
         if sig != self._slab_sig:
-            rc = self.lib.gmc_w1_slab_f32(hip.ptr(self.flat), self.N, self.F, hip.ptr(self.w1_slab), hip.stream())
+            rc = self.lib.gmc_w1_slab_f32(hip.ptr(self.flat), self.N, self.Fp, hip.ptr(self.w1_slab), hip.stream())
             hip.check(rc, "gmc_w1_slab_f32")
             self._slab_sig = sig
         return hip.ptr(self.w1_slab)
@@ -126,7 +139,7 @@ class FusedEngine:
         views = self.views()
         for k in PARAM_ORDER:
             p = named[k]
-            if p.data_ptr() != views[k].data_ptr() or p.device != self.device:
+            if p.data_ptr() != views[k].data_ptr() or p.device != self.device or p.stride() != views[k].stride():
                 views[k].copy_(p.detach().to(self.device, torch.float32))
                 p.data = views[k]
         self._adopted = [named[k] for k in PARAM_ORDER]
@@ -135,7 +148,8 @@ class FusedEngine:
     def owns(self, module: torch.nn.Module) -> bool:
         named = dict(module.named_parameters())
         views = self.views()
-        return all(named[k].data_ptr() == views[k].data_ptr() for k in PARAM_ORDER)
+        return all(named[k].data_ptr() == views[k].data_ptr() and named[k].stride() == views[k].stride()
+                   for k in PARAM_ORDER)
 
     def make_batch(self, handles, values=None) -> GraphBatch:
         return GraphBatch(handles, values, self.device)
@@ -204,8 +218,8 @@ class FusedEngine:
             loss = torch.empty(batch.B, dtype=torch.float32, device=self.device)
         else:
             P, S, loss = out
-        tail = (self.ensure_slab() if slab else None, hip.stream()) if hip.HAS_SLAB else (hip.stream(),)
-        rc = self.lib.gmc_train_step_f32(batch.ref(), self.N, self.F, hip.ptr(self.flat), C_, hip.ptr(ws), nbytes,
+        tail = (self.ensure_slab() if slab else None, hip.stream())
+        rc = self.lib.gmc_train_step_f32(batch.ref(), self.N, self.Fp, hip.ptr(self.flat), C_, hip.ptr(ws), nbytes,
                                          hip.ptr(P), hip.ptr(S), loss_ptr or hip.ptr(loss), hip.ptr(self.grad),
                                          hip.ptr(self.m), hip.ptr(self.v), lr, betas[0], betas[1], eps,
                                          hip.ptr(self.step_dev), *tail)
@@ -243,7 +257,7 @@ class FusedEngine:
         copy as well (which must be current: :meth:`ensure_slab`)."""
         if slab and self.slab_enabled:
             rc = self.lib.gmc_adam_devstep_model_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
-                                                     hip.ptr(self.v), self.N, self.F, self.ensure_slab(), lr, betas[0],
+                                                     hip.ptr(self.v), self.N, self.Fp, self.ensure_slab(), lr, betas[0],
                                                      betas[1], eps, hip.ptr(self.step_dev), hip.stream())
         else:
             rc = self.lib.gmc_adam_devstep_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),

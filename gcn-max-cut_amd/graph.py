@@ -176,21 +176,39 @@ class BatchArrays:
                 vals[eoff[g]:eoff[g + 1]] = values[g]
         degi = np.diff(rowptr)
         dinv = (1.0 / np.sqrt(np.maximum(degi.astype(np.float32), 1.0))).astype(np.float32)
-        # ELL copy for the LDS-tiled kernels: W slots per row (8 or 16), neighbours in CSR order,
-        # padded with the graph's node count (the id of the all-zero tile row) / weight 0
+        # ELL copy for the LDS-tiled kernels: W slots per row (8 or 16) holding the row's first W neighbours
+        # (CSR order, then re-arranged over the slots by the library), padded with the graph's node count (the id
+        # of an all-zero tile row) / weight 0.  Neighbours beyond the W-th of a row go to the overflow lists
+        # (blocks of eight ids per row): a hub node costs its own extra blocks, the batch stays on the LDS path.
         ell = ell_vals = None
+        ovf_ptr = ovf_ids = ovf_vals = None
         ell_slots = 0
         max_deg = int(degi.max()) if degi.size else 0
-        W = 8 if max_deg <= 8 else 16
-        if 0 < max_deg <= 16 and int(ns.max()) < 65535:
-            R = int(goff[-1])
-            slot = np.arange(int(eoff[-1]), dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), degi)
-            rows = np.repeat(np.arange(R, dtype=np.int64), degi)
-            ell = np.repeat(ns.astype(np.uint16), ns)[:, None].repeat(W, axis=1)
-            ell[rows, slot] = lcol.astype(np.uint16)
+        R = int(goff[-1])
+        W = self.choose_width(degi)
+        if W and int(ns.max()) < 65535:
+            deg64 = degi.astype(np.int64)
+            slot = np.arange(int(eoff[-1]), dtype=np.int64) - np.repeat(rowptr[:-1].astype(np.int64), deg64)
+            rows = np.repeat(np.arange(R, dtype=np.int64), deg64)
+            n_of_row = np.repeat(ns, ns)
+            inside = slot < W
+            ell = n_of_row.astype(np.uint16)[:, None].repeat(W, axis=1)
+            ell[rows[inside], slot[inside]] = lcol[inside].astype(np.uint16)
             if vals is not None:
                 ell_vals = np.zeros((R, W), np.float32)
-                ell_vals[rows, slot] = vals
+                ell_vals[rows[inside], slot[inside]] = vals[inside]
+            if max_deg > W:
+                blocks = (np.maximum(deg64 - W, 0) + 7) // 8
+                ovf_ptr = np.zeros(R + 1, np.int64)
+                np.cumsum(blocks, out=ovf_ptr[1:])
+                nblk = int(ovf_ptr[-1])
+                ovf_ids = np.repeat(n_of_row.astype(np.uint16), blocks * 8)       # padding: the zero row of the graph
+                where = ovf_ptr[:-1][rows[~inside]] * 8 + (slot[~inside] - W)
+                ovf_ids[where] = lcol[~inside].astype(np.uint16)
+                if vals is not None:
+                    ovf_vals = np.zeros(nblk * 8, np.float32)
+                    ovf_vals[where] = vals[~inside]
+                ovf_ptr = ovf_ptr.astype(np.int32)
             # LDS-bank-aware slot order (host routine of the library; plain CSR order otherwise)
             try:
                 lib = hip.load()
@@ -201,8 +219,8 @@ class BatchArrays:
                 go32 = goff.astype(np.int32)
                 rc = lib.gmc_ell_arrange_host(B, ptr(go32), ptr(rowptr), ptr(lcol), ptr(vals), W, ptr(ell), ptr(ell_vals))
                 hip.check(rc, "gmc_ell_arrange_host")
-                # 7 when no row of the batch has more than 7 neighbours: slot 7 of every row is then padding
-                ell_slots = int(lib.gmc_ell_slots_for(R, ptr(rowptr), W)) if hasattr(lib, "gmc_ell_slots_for") else 0
+                # s < W when no row of the batch has more than s neighbours: slots s.. of every row are then padding
+                ell_slots = int(lib.gmc_ell_slots_for(R, ptr(rowptr), W))
         self.B, self.R, self.nnz = B, int(goff[-1]), int(eoff[-1])
         self.n_max = int(ns.max()) if B else 0
         self.nnz_max = int(nnzs.max()) if B else 0
@@ -211,6 +229,23 @@ class BatchArrays:
         self.rowptr, self.gcol, self.lcol, self.vals, self.dinv = rowptr, gcol, lcol, vals, dinv
         self.ell, self.ell_vals, self.ell_width = ell, ell_vals, (W if ell is not None else 0)
         self.ell_slots = ell_slots if ell is not None else 0   # (without the library: CSR slot order, every slot live)
+        self.ovf_ptr, self.ovf_ids, self.ovf_vals = ovf_ptr, ovf_ids, ovf_vals
+        self.max_degree = max_deg
+
+    @staticmethod
+    def choose_width(degi: np.ndarray) -> int:
+        """Slots per row of the ELL table for rows of these degrees; 0 = no table (row kernels).  8 when (almost)
+        every row has at most 8 neighbours - up to one row in 200 may be longer, its extra neighbours become
+        overflow blocks - else 16 with the same allowance; no table once the overflow lists would hold more than
+        an eighth of the edges (dense graphs: the row kernels read those from HBM / L2 anyway)."""
+        if degi.size == 0 or int(degi.max()) <= 0:
+            return 0
+        R, nnz = degi.size, int(degi.sum())
+        for W in (8, 16):
+            over = degi > W
+            if int(over.sum()) * 200 <= R or (W == 16 and int((degi[over] - W).sum()) * 8 <= nnz):
+                return W
+        return 0
 
 
 class GraphBatch:
@@ -230,11 +265,15 @@ class GraphBatch:
         self.vals, self.dinv = dev(h.vals), dev(h.dinv)
         self.ell = None if h.ell is None else torch.from_numpy(h.ell.view(np.int16)).to(device)
         self.ell_vals = dev(h.ell_vals)
+        self.ovf_ptr = dev(h.ovf_ptr)
+        self.ovf_ids = None if h.ovf_ids is None else torch.from_numpy(h.ovf_ids.view(np.int16)).to(device)
+        self.ovf_vals = dev(h.ovf_vals)
         self.c = hip.GmcBatch(
             B=h.B, R=h.R, nnz=h.nnz, n_max=h.n_max, uniform_n=h.uniform_n, nnz_max=h.nnz_max,
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
             lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv),
-            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, ell_slots=h.ell_slots)
+            ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, ell_slots=h.ell_slots,
+            ovf_ptr=hip.ptr(self.ovf_ptr), ovf_ids=hip.ptr(self.ovf_ids), ovf_vals=hip.ptr(self.ovf_vals))
 
     def ref(self):
         return C.byref(self.c)

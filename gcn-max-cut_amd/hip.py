@@ -25,6 +25,7 @@ SYMBOLS = (
 
 MAX_GRAPH_NODES = 4096
 MODEL_GRAD_TAIL = 1   # gmc_model.flags: grad has a tail slot that receives the batch's loss sum
+ABI_VERSION = 200     # GMC_VERSION of include/gcnmaxcut.h these struct layouts follow (checked at load and per call)
 
 
 class HipExtensionError(RuntimeError):
@@ -33,25 +34,34 @@ class HipExtensionError(RuntimeError):
 
 class GmcBatch(C.Structure):
     _fields_ = [
-        ("B", C.c_int32), ("R", C.c_int32), ("nnz", C.c_int32), ("n_max", C.c_int32),
+        ("abi", C.c_int32), ("B", C.c_int32), ("R", C.c_int32), ("nnz", C.c_int32), ("n_max", C.c_int32),
         ("uniform_n", C.c_int32), ("nnz_max", C.c_int32),
         ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
         ("vals", C.c_void_p), ("dinv", C.c_void_p),
         ("ell", C.c_void_p), ("ell_vals", C.c_void_p), ("ell_width", C.c_int32), ("ell_slots", C.c_int32),
+        ("ovf_ptr", C.c_void_p), ("ovf_ids", C.c_void_p), ("ovf_vals", C.c_void_p),
     ]
+
+    def __init__(self, **kw):
+        kw.setdefault("abi", ABI_VERSION)
+        super().__init__(**kw)
 
 
 class GmcModel(C.Structure):
     _fields_ = [
-        ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
+        ("abi", C.c_int32), ("N", C.c_int32), ("F", C.c_int32), ("K", C.c_int32), ("flags", C.c_int32),
         ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p),
         ("dropout_p", C.c_float), ("dropout_seed_lo", C.c_uint32), ("dropout_seed_hi", C.c_uint32),
         ("W1_slab", C.c_void_p),
     ]
 
+    def __init__(self, **kw):
+        kw.setdefault("abi", ABI_VERSION)
+        super().__init__(**kw)
+
 
 _lib: Optional[C.CDLL] = None
-HAS_SLAB = False
+HAS_SLAB = True   # (every 0.2.x library has the W1 slab entry points; kept for callers that still ask)
 
 
 def _declare(lib: C.CDLL) -> None:
@@ -70,32 +80,23 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_backward_from_gp.argtypes = [C.POINTER(GmcBatch), C.POINTER(GmcModel), vp, sz, vp, vp, vp, vp]
     lib.gmc_adam_devstep_f32.argtypes = [vp, vp, vp, vp, i64, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.gmc_ell_arrange_host.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp]
-    if hasattr(lib, "gmc_ell_slots_for"):   # (absent from libraries built before round 2: A/B runs load those)
-        lib.gmc_ell_slots_for.argtypes = [i32, vp, i32]
-    # libraries built before the W1 slab copy existed (A/B runs load those) lack the three slab symbols and
-    # take gmc_train_step_f32 without its w1_slab argument: HAS_SLAB tells the engine which form to call
-    global HAS_SLAB
-    HAS_SLAB = hasattr(lib, "gmc_w1_slab_f32")
+    lib.gmc_ell_slots_for.argtypes = [i32, vp, i32]
     lib.gmc_train_step_f32.argtypes = [C.POINTER(GmcBatch), i32, i32, vp, f32, vp, sz, vp, vp, vp, vp, vp, vp,
-                                       C.c_double, C.c_double, C.c_double, C.c_double, vp] + ([vp, vp] if HAS_SLAB else [vp])
-    if HAS_SLAB:
-        lib.gmc_adam_devstep_model_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.c_double, C.c_double, C.c_double,
-                                                   C.c_double, vp, vp]
-        lib.gmc_w1_slab_floats.argtypes = [i32, i32]
-        lib.gmc_w1_slab_floats.restype = sz
-        lib.gmc_w1_slab_f32.argtypes = [vp, i32, i32, vp, vp]
+                                       C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+    lib.gmc_adam_devstep_model_f32.argtypes = [vp, vp, vp, vp, i32, i32, vp, C.c_double, C.c_double, C.c_double,
+                                               C.c_double, vp, vp]
+    lib.gmc_w1_slab_floats.argtypes = [i32, i32]
+    lib.gmc_w1_slab_floats.restype = sz
+    lib.gmc_w1_slab_f32.argtypes = [vp, i32, i32, vp, vp]
     lib.gmc_set_fuse.argtypes = [C.c_int]
     lib.gmc_decode_sample_f32.argtypes = [C.POINTER(GmcBatch), vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
     lib.gmc_probe_begin.argtypes = [i32]
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
-    if hasattr(lib, "gmc_host_device_pointer"):
-        lib.gmc_host_device_pointer.argtypes = [vp, C.POINTER(vp)]
-        lib.gmc_publish_f32.argtypes = [vp, i32, vp, vp]
+    lib.gmc_host_device_pointer.argtypes = [vp, C.POINTER(vp)]
+    lib.gmc_publish_f32.argtypes = [vp, i32, vp, vp]
+    lib.gmc_debug_set_device_cus.argtypes = [C.c_int]   # test hook (not part of gcnmaxcut.h)
+    lib.gmc_debug_set_device_cus.restype = C.c_int
     for name in SYMBOLS:
-        if name in ("gmc_ell_slots_for", "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32",
-                    "gmc_host_device_pointer", "gmc_publish_f32") \
-                and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)
         if name not in ("gmc_version", "gmc_error_string", "gmc_workspace_bytes", "gmc_w1_slab_floats"):
             fn.restype = C.c_int
@@ -110,6 +111,12 @@ def load() -> C.CDLL:
                 f"{LIB_PATH} is missing - build it with `python -c 'import __graft_entry__ as g; "
                 f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
+        lib.gmc_version.restype = C.c_int
+        have = int(lib.gmc_version())
+        if have != ABI_VERSION:   # struct layouts and signatures are chosen by VERSION, never by sniffing symbols
+            raise HipExtensionError(
+                f"{LIB_PATH} reports gmc_version() = {have}, this binding is written for {ABI_VERSION} "
+                f"(include/gcnmaxcut.h): rebuild the library (`python -c 'import __graft_entry__ as g; g.build()'`)")
         _declare(lib)
         _lib = lib
     return _lib
@@ -149,7 +156,7 @@ def mapped_ptr(t: torch.Tensor) -> Optional[int]:
     """Device-side address of a PINNED host tensor (kernels may store into it; the host polls it), or None when
     the library / runtime cannot map it."""
     lib = load()
-    if not (t.device.type == "cpu" and t.is_pinned() and t.is_contiguous() and hasattr(lib, "gmc_host_device_pointer")):
+    if not (t.device.type == "cpu" and t.is_pinned() and t.is_contiguous()):
         return None
     out = C.c_void_p()
     if lib.gmc_host_device_pointer(C.c_void_p(t.data_ptr()), C.byref(out)) != 0 or not out.value:

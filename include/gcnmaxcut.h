@@ -28,7 +28,11 @@
 extern "C" {
 #endif
 
-#define GMC_VERSION 100 /* 0.1.0 */
+/* 0.2.0.  Incompatible with 0.1.x: gmc_batch and gmc_model start with an `abi` word and gmc_batch carries the
+ * overflow lists, so callers compiled against a 0.1.x header must be recompiled ("ABI versions").
+ * Every entry point that takes one of the two structs checks its `abi` word and returns GMC_ERR_ABI on a
+ * mismatch instead of reading a differently laid out struct. */
+#define GMC_VERSION 200
 
 typedef void *gmc_stream_t; /* hipStream_t */
 
@@ -40,7 +44,8 @@ enum {
     GMC_ERR_ALIGN = -4,       /* pointer / leading dimension not 16-byte aligned */
     GMC_ERR_WORKSPACE = -5,   /* workspace too small */
     GMC_ERR_GRAPH_SIZE = -6,  /* a graph has < 3 or > GMC_MAX_GRAPH_NODES nodes */
-    GMC_ERR_UNSUPPORTED = -7
+    GMC_ERR_UNSUPPORTED = -7,
+    GMC_ERR_ABI = -8          /* gmc_batch.abi / gmc_model.abi != GMC_VERSION: caller built against another header */
 };
 
 #define GMC_MAX_GRAPH_NODES 4096 /* per-graph head kernel keeps [n,3] tiles in LDS */
@@ -50,6 +55,7 @@ enum {
  * the DGL graph == CSR structure, the padded adjacency == `vals` on that structure).
  * Built once per dataset by the host (gcn-max-cut_amd/graph.py). */
 typedef struct gmc_batch {
+    int32_t abi;           /* GMC_VERSION of the header the caller was compiled against (checked) */
     int32_t B;             /* graphs in the batch */
     int32_t R;             /* total nodes = sum n_g */
     int32_t nnz;           /* total directed edges = sum 2|E_g| */
@@ -63,21 +69,32 @@ typedef struct gmc_batch {
     const float *vals;     /* [nnz] edge weight = X[u,v], or NULL when all ones */
     const float *dinv;     /* [R] clamp(degree,1)^-1/2  (in == out degree: undirected) */
     /* Optional ELL copy of the same structure for the LDS-tiled kernels (NULL: row kernels
-     * only): W = ell_width slots per row (8 or 16, >= max degree), local neighbour ids in the
-     * order gmc_ell_arrange_host chose, padded with n_g..n_g+3 (all-zero tile rows), weights 0. */
+     * only): W = ell_width slots per row (8 or 16), the row's FIRST min(degree, W) neighbours (CSR order) as
+     * local ids in the slot order gmc_ell_arrange_host chose, padded with n_g..n_g+3 (all-zero tile rows),
+     * weights 0.  Neighbours beyond the W-th of a row live in the overflow lists below. */
     const uint16_t *ell;   /* [R][W] */
     const float *ell_vals; /* [R][W] or NULL when all ones */
     int32_t ell_width;
-    /* neighbour slots that can hold a neighbour: 0 or ell_width = all of them; 7 (ell_width 8 only) = slot 7
-     * of EVERY row is padding, which is how gmc_ell_arrange_host lays out a batch whose largest degree is
-     * <= 7 (d = 7 regular graphs, the headline workload) - the LDS-tiled kernels then neither read nor add
-     * that slot.  (Was `reserved`, 0.) */
+    /* leading slots of a row that can hold a neighbour: 0 or ell_width = all of them; s < ell_width = slots
+     * s..ell_width-1 of EVERY row are padding (gmc_ell_arrange_host lays a batch out that way when no row has
+     * more than s neighbours, gmc_ell_slots_for tells s) - the LDS-tiled kernels then neither read nor add
+     * those slots: 7 of 8 for d = 7 regular graphs (the headline workload), 12 of 16 for d = 12. */
     int32_t ell_slots;
+    /* Overflow lists (NULL: no row of the batch has more than ell_width neighbours): the neighbours of row r
+     * beyond its first ell_width, CSR order, in blocks of 8 local ids - blocks ovf_ptr[r] .. ovf_ptr[r+1]-1,
+     * i.e. ids ovf_ids[8*ovf_ptr[r] ..), the last block of a row padded with n_g (weight 0).  A row with a
+     * hub's degree then costs its own extra blocks (a short tail loop of the thread that owns the row)
+     * instead of moving the whole batch to the row kernels.  Summation order of a row: ELL slots, then the
+     * overflow blocks in order. */
+    const int32_t *ovf_ptr;   /* [R+1] in blocks, or NULL */
+    const uint16_t *ovf_ids;  /* [8 * ovf_ptr[R]] */
+    const float *ovf_vals;    /* [8 * ovf_ptr[R]] or NULL when all ones */
 } gmc_batch;
 
 /* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):
  * conv1.weight [N,F], conv1.bias [F], conv2.weight [F,K], conv2.bias [K]. */
 typedef struct gmc_model {
+    int32_t abi;   /* GMC_VERSION of the header the caller was compiled against (checked) */
     int32_t N, F, K;
     int32_t flags; /* GMC_MODEL_* bits, 0 by default */
     const float *W1, *b1, *W2, *b2;
@@ -110,12 +127,14 @@ const char *gmc_error_string(int code);
  * its CSR.  Inside each group of four rows that share an LDS cycle of the tiled kernels the
  * neighbours are ordered over the W slots so that a slot's four fetches fall into different LDS
  * bank quarters where possible; padding entries are n_g .. n_g+3 (four all-zero tile rows).
- * The slot order is the summation order of the LDS-tiled kernels (fixed per batch).  With W == 8 and no
- * row of the batch longer than 7 the neighbours are arranged over slots 0..6 and slot 7 of every row is
- * padding: set gmc_batch.ell_slots = 7 for such a batch (gmc_ell_slots_for tells). */
+ * The slot order is the summation order of the LDS-tiled kernels (fixed per batch).  When no row of the
+ * batch is longer than s = gmc_ell_slots_for(...) < W the neighbours are arranged over slots 0..s-1 and slots
+ * s..W-1 of every row are padding: set gmc_batch.ell_slots = s for such a batch.  Of a row longer than W
+ * the first W neighbours (CSR order) are placed; the caller puts the rest into the overflow lists. */
 int gmc_ell_arrange_host(int32_t B, const int32_t *goff, const int32_t *rowptr, const int32_t *lcol,
                          const float *vals, int32_t W, uint16_t *ell, float *ell_vals);
-/* the slots gmc_ell_arrange_host uses for a batch with R rows (host pointer): 7 or W */
+/* the slots gmc_ell_arrange_host uses for a batch with R rows (host pointer): the largest row length,
+ * at least 7 (W = 8) / 9 (W = 16), at most W */
 int gmc_ell_slots_for(int32_t R, const int32_t *rowptr, int32_t W);
 
 /* Kernel tags reported by the timing probe (one per launch of the fused step). */

@@ -22,7 +22,9 @@ def test_library_exports_every_declared_symbol(built):
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(built.hip.SYMBOLS) == names
-    assert lib.gmc_version() == 100
+    assert lib.gmc_version() == 200 == built.hip.ABI_VERSION     # 0.2.0: structs start with an `abi` word
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "gcnmaxcut.h")).read()
+    assert re.search(r"#define\s+GMC_VERSION\s+200\b", header)
     assert lib.gmc_error_string(-3).decode().startswith("number_classes must be 3")
 
 
@@ -76,3 +78,32 @@ def test_argument_errors_need_no_gpu(built):
     assert lib.gmc_adam_devstep_model_f32(some, some, some, some, 1000, 501, null, 1e-3, 0.9, 0.999, 1e-8, some, None) == -2
     assert lib.gmc_adam_devstep_model_f32(some, some, some, some, 1000, 500, C.c_void_p(4100), 1e-3, 0.9, 0.999, 1e-8,
                                           some, None) == -4
+
+
+def test_structs_carry_the_abi_word_and_it_is_checked(built):
+    """gmc_batch / gmc_model start with the GMC_VERSION the caller was compiled against; an entry point given a
+    struct of another version refuses (GMC_ERR_ABI) before it reads any other field - no GPU needed."""
+    import ctypes as C
+    hip = built.hip
+    lib = hip.load()
+    assert hip.GmcBatch._fields_[0][0] == "abi" and hip.GmcModel._fields_[0][0] == "abi"
+    assert hip.GmcBatch().abi == hip.ABI_VERSION and hip.GmcModel().abi == hip.ABI_VERSION
+    names = [f[0] for f in hip.GmcBatch._fields_]
+    assert names[-3:] == ["ovf_ptr", "ovf_ids", "ovf_vals"] and "ell_slots" in names
+    old_b, old_m = hip.GmcBatch(abi=100), hip.GmcModel(abi=100)
+    some = C.c_void_p(4096)
+    assert lib.gmc_workspace_bytes(C.byref(hip.GmcBatch()), C.byref(hip.GmcModel()), 1) >= 0
+    assert lib.gmc_forward(C.byref(old_b), C.byref(hip.GmcModel()), 1.0, some, 1 << 20, some, None, None, None) == -8
+    assert lib.gmc_forward(C.byref(hip.GmcBatch()), C.byref(old_m), 1.0, some, 1 << 20, some, None, None, None) == -8
+    assert lib.gmc_head_f32(C.byref(old_b), some, 1, some, 1.0, some, None, None, None, None, None) == -8
+    assert b"GMC_VERSION" in lib.gmc_error_string(-8)
+
+
+def test_shipped_library_reads_no_tuning_environment(built):
+    """The tuning switches (GMC_LDS_MAX_FS, GMC_SPMM_TUNE, ...) exist only in `make variant DEFS=-DGMC_TUNING`
+    builds: a stray variable in a user's shell cannot change kernel shapes or summation orders."""
+    blob = open(built.hip.LIB_PATH, "rb").read()
+    for name in (b"GMC_LDS_MAX_FS", b"GMC_DEVICE_CUS", b"GMC_SPMM_TUNE", b"GMC_DW1_CHUNKS", b"GMC_LDS_SLICES_PER_WG",
+                 b"GMC_SPMM_ALGO", b"GMC_FUSE"):
+        assert name not in blob, name
+    assert b"getenv" not in blob or True   # (the C runtime may import it; the names above are what matters)

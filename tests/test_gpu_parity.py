@@ -235,16 +235,19 @@ def test_persistent_forward_ranges_cross_graphs(pkg, monkeypatch):
     specs = [(300, 7, 41), (120, 6, 42), (1000, 7, 43), (64, 5, 44), (500, 8, 45), (250, 7, 46), (90, 6, 47)]
     items = list(util.product_dataset(specs).values())
     batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
-    monkeypatch.setenv("GMC_DEVICE_CUS", "100000")   # one item per workgroup
-    P1, S1, l1 = [t.clone() for t in eng.forward(batch, 1.0, want_loss=True)]
-    for cus in ("4", "3", "1"):
-        monkeypatch.setenv("GMC_DEVICE_CUS", cus)
-        P2, S2, l2 = eng.forward(batch, 1.0, want_loss=True)
-        assert torch.equal(P1, P2) and torch.equal(S1, S2) and torch.equal(l1, l2), cus
-    monkeypatch.setenv("GMC_DEVICE_CUS", "3")
-    eng.train_fwd_bwd(batch, 1.0)
-    g3 = eng.grad.clone()
-    monkeypatch.delenv("GMC_DEVICE_CUS")
+    lib = pkg.hip.load()
+    try:
+        lib.gmc_debug_set_device_cus(100000)   # one item per workgroup
+        P1, S1, l1 = [t.clone() for t in eng.forward(batch, 1.0, want_loss=True)]
+        for cus in (4, 3, 1):
+            lib.gmc_debug_set_device_cus(cus)
+            P2, S2, l2 = eng.forward(batch, 1.0, want_loss=True)
+            assert torch.equal(P1, P2) and torch.equal(S1, S2) and torch.equal(l1, l2), cus
+        lib.gmc_debug_set_device_cus(3)
+        eng.train_fwd_bwd(batch, 1.0)
+        g3 = eng.grad.clone()
+    finally:
+        lib.gmc_debug_set_device_cus(0)
     eng.train_fwd_bwd(batch, 1.0)
     assert torch.equal(g3, eng.grad)
 
@@ -332,52 +335,7 @@ def flat_ref_grads(ct):
 def test_step_gradients_match_oracle(pkg, hidden, specs):
     T, cfg, net, embed, opt, params = model_and_params(pkg, hidden)
     ds = util.product_dataset(specs)
-    eng = net.engine()
-    items = list(ds.values())
-    batch = pkg.GraphBatch([it[0] for it in items], None, eng.device)
-    eng.train_fwd_bwd(batch, 1.0)      # sizes the workspace ...
-    eng._ws.fill_(255)                 # ... which is then poisoned (all-ones bytes = NaN): nothing may be
-    eng.grad.fill_(float("nan"))       # read before it is written in the same step
-    P, S, loss = eng.train_fwd_bwd(batch, 1.0)
-    ct = CO.CTrainer(params)
-    csrs = util.csrs_of(ds)
-    ref_loss = ct.step(csrs)
-    loss_np, S_np = loss.cpu().numpy(), S.cpu().numpy()
-    if not np.array_equal(loss_np, ref_loss):
-        # A graph whose loss differs decoded some row differently.  That is legitimate only on a near-tie (the
-        # summation order of the kernels is not the oracle's: top-2 margin inside fp32 noise); the gradient of
-        # such a graph is then the oracle's backward for the partition the KERNELS chose, which is what is built
-        # here: same forward, GP from the kernels' S, same backward.
-        W = [params[k] for k in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias")]
-        acc = [np.zeros_like(w) for w in W]
-        off = 0
-        for i, (rp, cl, vl) in enumerate(csrs):
-            n = len(rp) - 1
-            f = CO.forward(rp, cl, vl, *W)
-            ref_s = f["P"].argmax(1); ref_s[:3] = [0, 1, 2]
-            s_i = S_np[off:off + n]
-            diff = np.nonzero(s_i != ref_s)[0]
-            if diff.size == 0:
-                assert loss_np[i] == ref_loss[i], i
-            else:
-                srt = np.sort(f["P"][diff].astype(np.float64), axis=1)
-                assert (srt[:, 2] - srt[:, 1]).max() < 1e-6, (i, diff, srt)
-            wv = np.ones(len(cl), np.float32) if vl is None else vl
-            rows = np.repeat(np.arange(n), np.diff(rp))
-            GP = np.zeros((n, 3), np.float32)
-            np.add.at(GP, (rows, s_i[cl]), wv)                     # GP = C * A_val @ onehot(S), C = 1
-            cut = 0.5 * float(wv[s_i[rows] != s_i[cl]].sum())
-            assert loss_np[i] == -cut, i                            # loss == -cut of the partition the kernels chose
-            for a_, d_ in zip(acc, CO.backward(rp, cl, vl, W[0].shape[0], W[2], f["H"], f["P"], GP)):
-                a_ += d_
-            off += n
-        ref = dict(zip(("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"), [a_.ravel() for a_ in acc]))
-    else:
-        ref = flat_ref_grads(ct)
-    assert float(eng.grad[eng.count]) == float(loss_np.sum())   # GMC_MODEL_GRAD_TAIL: the loss rides behind the gradient
-    for k, g in eng.views(eng.grad).items():
-        g, r = g.cpu().numpy().ravel(), ref[k]
-        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), k
+    eng, _tags = util.check_step_against_oracle(pkg, net, ds, params)
     # rows of dW1 that no graph reaches are exactly zero
     nmax = max(s[0] for s in specs)
     assert float(eng.views(eng.grad)["conv1.weight"][nmax:].abs().max() if nmax < 1000 else 0.0) == 0.0

@@ -120,6 +120,48 @@ def test_batch_layout_csr_and_ell(built):
     assert built.BatchArrays([big]).ell is None                     # degree > 16: row kernels only
 
 
+def test_batch_layout_table_width_and_overflow_lists(built):
+    """Rows longer than the table: the first W neighbours (CSR order) sit in the ELL row, the rest in blocks of
+    eight overflow ids (padded with the graph's zero row); the table is 8 wide while at most one row in 200 is
+    longer than 8, else 16; `ell_slots` = the largest row length the table has to hold."""
+    hub = R.regular_graph(1000, 7, 5)
+    for v in range(10, 43):
+        hub.add_edge(3, v)
+    hs = [built.from_networkx(hub), built.from_networkx(R.regular_graph(600, 7, 6))]
+    b = built.BatchArrays(hs)
+    assert (b.ell_width, b.ell_slots, b.max_degree) == (8, 8, 40)
+    assert b.ovf_ptr.dtype == np.int32 and b.ovf_ptr.shape == (1601,) and int(b.ovf_ptr[-1]) == 4
+    assert b.ovf_ids.shape == (32,) and b.ovf_vals is None
+    for g, h in enumerate(hs):
+        r0 = int(b.goff[g])
+        for l in range(h.n):
+            nb = h.col[h.rowptr[l]:h.rowptr[l + 1]].tolist()
+            slots = [x for x in b.ell[r0 + l].tolist() if x < h.n]
+            extra = b.ovf_ids[8 * b.ovf_ptr[r0 + l]:8 * b.ovf_ptr[r0 + l + 1]].tolist()
+            assert sorted(slots) == sorted(nb[:8])
+            assert [x for x in extra if x < h.n] == nb[8:] and all(x == h.n for x in extra[len(nb) - 8:] if len(nb) > 8)
+    # weighted: overflow weights follow their ids, padding weighs 0
+    for u, v in hub.edges():
+        hub[u][v]["weight"] = 1 + (u + v) % 3
+    hw = built.from_networkx(hub)
+    bw = built.BatchArrays([hw])
+    l = 3
+    w_csr = hw.weight[hw.rowptr[l]:hw.rowptr[l + 1]]
+    assert np.array_equal(bw.ovf_vals[:32], w_csr[8:].astype(np.float32))
+    # widths
+    cw = built.BatchArrays.choose_width
+    assert cw(np.full(1000, 7)) == 8 and cw(np.full(1000, 8)) == 8 and cw(np.full(1000, 9)) == 16
+    assert cw(np.r_[np.full(995, 7), np.full(5, 30)]) == 8          # 1 row in 200
+    assert cw(np.r_[np.full(994, 7), np.full(6, 30)]) == 16
+    assert cw(np.full(64, 20)) == 0                                  # overflow lists > 1/8 of the edges: row kernels
+    d12 = built.BatchArrays([built.from_networkx(R.regular_graph(100, 12, 1))])
+    assert (d12.ell_width, d12.ell_slots, d12.ovf_ptr) == (16, 12, None)
+    d9 = built.BatchArrays([built.from_networkx(R.regular_graph(100, 9, 1)), built.from_networkx(R.regular_graph(50, 6, 1))])
+    assert (d9.ell_width, d9.ell_slots) == (16, 9)
+    # slots beyond ell_slots are padding in EVERY row (the kernels do not read them)
+    assert (d12.ell[:, 12:] >= 100).all() and (d9.ell[:, 9:] >= np.repeat([100, 50], [100, 50])[:, None]).all()
+
+
 def test_early_stopping_best_tracking_and_checkpoints(T, tmp_path, monkeypatch):
     """train_model's bookkeeping (TrainingNeural.py:421-482) with a scripted loss sequence."""
     monkeypatch.chdir(tmp_path)
