@@ -15,13 +15,21 @@ graphs are split over the ranks (160/N each - BASELINE config[3] literally at N=
 line of a weak run also carries `strong_scaling`, the same job re-timed on the strong split.
 
 The JSON line also carries
-  roofline      - the SpMM the metric names (LDS-tiled CSR SpMM of the layer-1 aggregation,
-                  forward + backward launches): algorithmic bytes / mean launch duration, HIP
-                  events recorded by the library on the launch stream during a
-                  region of K steps run as one kernel per operation (gmc_set_fuse(0));
-  roofline_step - the dominant kernel of the TIMED (default, fused) step, priced on the bytes it
-                  must move (compulsory) with the PMC-measured traffic beside them; the other fused
-                  kernel under `also`;
+  roofline      - the DOMINANT KERNEL OF THE TIMED STEP (the fused backward or forward of layer 1): the bytes it must
+                  move per launch (compulsory = algorithmic: H once + tables + partials) / its mean launch duration,
+                  HIP events recorded by the library on the launch stream over K eager steps; `traffic` = PMC bytes
+                  from profiles/traffic_fused.json when that file was measured on these very kernel sources (else
+                  null); `lds` = the same launch priced on LDS bytes (gathers + tile writes) against the LDS peak -
+                  the resource the fused kernels' time actually goes into (`limited_by`); the other fused kernel
+                  under `also`;
+  roofline_spmm - the SpMM the metric names (LDS-tiled CSR SpMM of the layer-1 aggregation, forward + backward
+                  launches of a region of K steps run as one kernel per operation, gmc_set_fuse(0)) on SURVEY 8(d)'s
+                  algorithmic bytes, plus `by_batch`: the same kernel at B = 1 / 20 / 160 / 1024 graphs;
+  other_workloads - the same step on 160 x n=1000 graphs of degree 8, degree 12 and G(n, p=0.01) graphs (the
+                  reference's generator, GraphCreator.py:70-78): ms per step, per-kernel us, parity gate;
+  dp_shard_profile - the data-parallel step sequence on ONE rank over RCCL at the strong split's shard sizes
+                  (20 / 40 / 80 / 160 graphs), eager launches vs hipGraphs: ms per step, per-kernel us, host
+                  enqueue time, single-rank all-reduce us (N = 1 runs only; a model input, not a scaling claim);
   sequential    - the reference's own schedule (one Adam step per graph, TrainingNeural.py:371-386)
                   on the same 160 graphs, one hipGraph per epoch: the like-for-like partner of
   cpu_baseline  - the CPU oracle timed on this box's host cores on a bounded sample, rank 0, N=1 only:
@@ -29,11 +37,12 @@ The JSON line also carries
                   GEMM, per-row Python one-hot, dense loss, one Adam step per graph) at torch's default
                   thread count, at 16 and at 1 thread (`value` = the best of them, `cores` says which);
                   variant B = oracle/gcn_oracle.c (scalar C: CSR SpMM, fused
-                  argmax / loss), 1 thread.
+                  argmax / loss), 1 thread.  Both GPU/CPU ratios are printed (neither is a quality claim).
 
-Order of the regions inside one run: `sequential`, the per-kernel probe (150 untimed + K eager steps with HIP
-events around every kernel), the one-kernel-per-operation leg, and LAST the headline: W untimed warmup steps,
-then exactly K timed steps between barrier + synchronize pairs.  A fresh process needs ~30 steps to reach the
+Order of the regions inside one run: graph generation (worker processes, before the GPU is touched), `sequential`,
+the per-kernel probe (150 untimed + K eager steps with HIP events around every kernel), the one-kernel-per-operation
+leg + SpMM batch sweep, the other workloads, the data-parallel shard profile, and LAST the headline: W untimed warmup
+steps, then exactly K timed steps between barrier + synchronize pairs.  A fresh process needs ~30 steps to reach the
 clocks the chip sustains; with the headline last its timed steps are sustained-clock steps at any K / W.
 """
 from __future__ import annotations
@@ -56,6 +65,7 @@ import torch.distributed as dist
 
 EPOCH_GRAPHS = 160  # BASELINE.json configs[3]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+LDS_PEAK_GBS = 256 * 256 * 2.4  # MI355X_MICROARCH.md, LDS: 256 B/clk/CU x 256 CUs x 2.4 GHz max clock = 157,286 GB/s
 
 
 def parse():
@@ -77,6 +87,9 @@ def parse():
     ap.add_argument("--no-sequential", action="store_true", help="skip the reference-schedule region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the d=8 / d=12 / G(n,p) steps")
+    ap.add_argument("--no-dp-profile", action="store_true", help="skip the single-rank data-parallel shard profile")
+    ap.add_argument("--no-spmm-sweep", action="store_true", help="skip the SpMM batch-size sweep")
     return ap.parse_args()
 
 
@@ -93,16 +106,74 @@ def regular_graph(n, d, seed):
     return g
 
 
+def gnp_graph(n, p, seed):
+    """G(n,p) as the reference's generator builds it (GraphCreator.py:76: graph_type 'prob' = fast_gnp_random_graph),
+    re-drawn with another seed while a node is isolated (DGL's GraphConv refuses zero in-degree nodes)."""
+    import networkx as nx
+    while True:
+        tmp = nx.convert_node_labels_to_integers(nx.fast_gnp_random_graph(n, p, seed=seed))
+        if min(d for _, d in tmp.degree()) > 0:
+            break
+        seed += 100000
+    g = nx.Graph()
+    g.add_nodes_from(sorted(tmp.nodes()))
+    g.add_edges_from(tmp.edges)
+    nx.set_edge_attributes(g, 1, "weight")
+    nx.set_edge_attributes(g, 1, "capacity")
+    return g
+
+
+def _make_graph(spec):
+    kind, n, par, seed = spec
+    return regular_graph(n, par, seed) if kind == "reg" else gnp_graph(n, par, seed)
+
+
+def generate(specs):
+    """networkx graphs of [(kind, n, degree-or-p, seed), ...] on a few worker processes.  Called BEFORE this process
+    touches the GPU (forked workers and an initialised HIP runtime do not mix)."""
+    import multiprocessing as mp
+    workers = max(1, min(8, (os.cpu_count() or 2) // 2, len(specs)))
+    if workers == 1:
+        return [_make_graph(sp) for sp in specs]
+    with mp.get_context("fork").Pool(workers) as pool:
+        return pool.map(_make_graph, specs, chunksize=max(1, len(specs) // (4 * workers)))
+
+
 def terminals_of(n, seed):
+    """Three seeded terminals (the reference draws them unseeded, GraphCreator.py:109); a draw holding two or more
+    of the nodes 0, 1, 2 is drawn again - process_graphs_from_folder SKIPS such a graph (graphExtender.py:72-97)."""
     import random
-    return random.Random(seed).sample(range(n), 3)
+    while True:
+        t = random.Random(seed).sample(range(n), 3)
+        if len(set(t) & {0, 1, 2}) < 2:
+            return t
+        seed += 100000
+
+
+def csrc_fingerprint():
+    """sha256 over the kernel sources: profiles/traffic_*.json carry the fingerprint they were measured on, and a
+    PMC figure is quoted only for the sources it belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "gcn-max-cut_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "gcn-max-cut_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def free_port():
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
 
 
 def self_launch(args) -> int:
     """`bench.py --gpus N` without a rendezvous environment: start the N ranks as CHILD processes
     (torch.distributed.run) before this process has touched a GPU, hand their output through and return
     their exit status.  Nothing here initialises HIP (device_count() does not)."""
-    import socket
     import subprocess
     rehearse = os.environ.get("GCN_MAXCUT_BENCH_REHEARSE") == "1"
     have = torch.cuda.device_count()
@@ -110,9 +181,7 @@ def self_launch(args) -> int:
         print(f"bench.py: --gpus {args.gpus} but {have} HIP device(s) visible; refusing to launch "
               f"(set GCN_MAXCUT_BENCH_REHEARSE=1 to rehearse N ranks on one device over gloo)", file=sys.stderr)
         return 2
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -133,16 +202,41 @@ def main():
     rehearse = os.environ.get("GCN_MAXCUT_BENCH_REHEARSE") == "1"
     if rehearse:
         local = 0
-    torch.cuda.set_device(local)
-    backend = None
     # GCN_MAXCUT_DP_SINGLE_RANK=1 (one-GPU boxes): ONE rank over RCCL runs the data-parallel step sequence -
     # communicator set-up, the collective on the launch stream and graph capture beside RCCL's threads
     single_dp = world == 1 and os.environ.get("GCN_MAXCUT_DP_SINGLE_RANK") == "1"
     dp = world > 1 or single_dp
+    if args.mode == "sequential" and world > 1:
+        raise SystemExit("sequential mode is the single-GPU reference schedule")
+    if args.graphs_per_gpu is None:
+        args.graphs_per_gpu = EPOCH_GRAPHS if args.scaling == "weak" else max(1, EPOCH_GRAPHS // world)
+    gpg, n, d = args.graphs_per_gpu, args.nodes, args.degree
+
+    # ---- synthetic inputs, generated on worker processes BEFORE this process touches the GPU
+    extras_on = (not dp and args.mode == "batched" and not args.no_other_workloads and not args.no_probe)
+    seeds = [3000 + rank * gpg + i for i in range(gpg)]
+    specs = [("reg", n, d, sd) for sd in seeds]
+    extra_defs = []
+    n_other = EPOCH_GRAPHS if gpg >= EPOCH_GRAPHS else gpg   # (reduced runs, e.g. the contract test: as many as the headline)
+    if extras_on:   # GraphCreator.py:70-78,151-152: regular graphs of degree min..max and G(n,p) graphs
+        extra_defs = [("d8", "reg", 8, 8000, f"{n_other} x n={n} d=8 regular graphs (8-slot table, every slot live)"),
+                      ("d12", "reg", 12, 12000, f"{n_other} x n={n} d=12 regular graphs (16-slot table, 12 live)"),
+                      ("gnp", "gnp", 10.0 / n, 20000, f"{n_other} x G(n={n}, p={10.0 / n:g}) graphs, mean degree 10 "
+                       "(GraphCreator 'prob'; 16-slot table + overflow lists for the rows beyond 16)")]
+        for _name, kind, par, base, _what in extra_defs:
+            specs += [(kind, n, par, base + i) for i in range(n_other)]
+    t_gen = time.perf_counter()
+    made = generate(specs)
+    t_gen = time.perf_counter() - t_gen
+    graphs = dict(enumerate(made[:gpg]))
+    terms = {i: terminals_of(n, s) for i, s in enumerate(seeds)}
+
+    torch.cuda.set_device(local)
+    backend = None
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if single_dp:
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -152,37 +246,43 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         backend = dist.get_backend()
         world = dist.get_world_size()      # what the collective library saw, not what the flag said
-    if args.mode == "sequential" and world > 1:
-        raise SystemExit("sequential mode is the single-GPU reference schedule")
-    if args.graphs_per_gpu is None:
-        args.graphs_per_gpu = EPOCH_GRAPHS if args.scaling == "weak" else max(1, EPOCH_GRAPHS // world)
 
     import gcn_max_cut_amd as pkg
     from gcn_max_cut_amd.DataGenerator import graphExtender as GE
     from gcn_max_cut_amd.Training import TrainingNeural as T
 
-    gpg, n, d = args.graphs_per_gpu, args.nodes, args.degree
-    seeds = [3000 + rank * gpg + i for i in range(gpg)]
-    graphs = {i: regular_graph(n, d, s) for i, s in enumerate(seeds)}
-    terms = {i: terminals_of(n, s) for i, s in enumerate(seeds)}
-    with contextlib.redirect_stdout(io.StringIO()):
-        dataset = GE.process_graphs_from_folder(graphs, terms, 1000)
-    assert len(dataset) == gpg, "a synthetic graph was skipped by the terminal normalisation"
+    def extend(gs, ts):
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds = GE.process_graphs_from_folder(gs, ts, 1000)
+        assert len(ds) == len(gs), "a synthetic graph was skipped by the terminal normalisation"
+        return ds
 
+    dataset = extend(graphs, terms)
     cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=args.hidden, number_epochs=10 ** 9, patience=10 ** 9)
-    torch.manual_seed(0)  # CPU RNG: identical Xavier init on every rank
-    net, embed, opt = T.setup_model_and_optimizer(cfg)
+
+    def fresh_model():
+        torch.manual_seed(0)  # CPU RNG: identical Xavier init on every rank
+        net_, embed_, opt_ = T.setup_model_and_optimizer(cfg)
+        net_.train()
+        return net_, embed_, opt_
+
+    net, embed, opt = fresh_model()
     gps = gpg if args.mode == "batched" else 1
     trainer = T.FusedTrainer(net, opt, cfg, graphs_per_step=gps, local_shard=True)
-    net.train()
     trainer.prepare(dataset)
     eng = trainer.eng
-    spmm_bytes = trainer._batches[0].spmm_bytes(args.hidden)
+    spmm_bytes = trainer._batches[0].spmm_bytes(eng.Fp)
 
     def sync():
-        if dp:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
+
+    t_start = time.perf_counter()
+
+    def note(what):   # region timings on stderr (the JSON line is the only thing on stdout)
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {what}", file=sys.stderr, flush=True)
 
     def timed(tr, data, warmup, steps):
         """W untimed steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks."""
@@ -195,11 +295,30 @@ def main():
             loss = tr.epoch(data)
         sync()
         dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if dp:
+        if dist.is_initialized():
             dist.all_reduce(dt, op=dist.ReduceOp.MAX)
         return float(dt.item()), loss
 
-    launches_per_step = 16 * len(trainer._batches)
+    def probed(tr, data, untimed, steps):
+        """Per-kernel mean milliseconds over `steps` eager steps (HIP events recorded by the library on the launch
+        stream around every kernel; a graph replay cannot carry them), after `untimed` eager steps."""
+        was = tr.allow_graph
+        tr.allow_graph = False
+        for _ in range(untimed):
+            tr.epoch(data)
+        sync()
+        te = time.perf_counter()
+        with pkg.hip.Probe(16 * max(1, len(tr._batches)) * steps) as probe:
+            for _ in range(steps):
+                tr.epoch(data)
+            sync()
+        wall_ms = 1e3 * (time.perf_counter() - te) / steps
+        tr.allow_graph = was
+        by = {}
+        for tag, ms in probe.records:
+            by.setdefault(tag, []).append(ms)
+        return {k: float(np.mean(v)) for k, v in by.items()}, by, wall_ms
+
     # Order of the regions: the reference-schedule run, the per-kernel probe and the one-kernel-per-operation leg
     # come FIRST, the headline's W warmup + K timed steps LAST: a freshly started process needs ~30 steps (7 ms)
     # to reach the clocks the chip sustains, and training throughput is a sustained quantity.
@@ -207,9 +326,7 @@ def main():
     # one hipGraph per epoch - what `cpu_baseline` (same schedule, host cores) is to be compared with
     sequential = None
     if not dp and args.mode == "batched" and not args.no_sequential:
-        torch.manual_seed(0)
-        net_s, embed_s, opt_s = T.setup_model_and_optimizer(cfg)
-        net_s.train()
+        net_s, embed_s, opt_s = fresh_model()
         tr_q = T.FusedTrainer(net_s, opt_s, cfg, graphs_per_step=1, local_shard=True)
         k_seq = max(3, args.steps // 10)
         dt, _ = timed(tr_q, dataset, 2, k_seq)
@@ -217,49 +334,92 @@ def main():
                       "ms_per_epoch": 1e3 * dt / k_seq, "us_per_graph_step": 1e6 * dt / (k_seq * gpg),
                       "optimizer_steps_per_epoch": gpg, "epochs_timed": k_seq,
                       "schedule": "one Adam step per graph, dataset order (reference schedule), hipGraph per epoch"}
+        del tr_q, net_s, embed_s, opt_s
+        note("reference-schedule region done")
 
-    # per-kernel means: the same K steps repeated with eager launches, every kernel bracketed by
-    # HIP events on the launch stream (a graph replay cannot carry the probe's event records)
-    kernels = {}
-    eager_ms = None
+    # per-kernel means of the default (fused) step: 150 untimed eager steps (kernel set-up; ~40 ms of full load bring
+    # the chip to its sustained clocks after the light reference-schedule region), then K probed ones -> `roofline`
+    kmean, eager_ms = {}, None
     if not args.no_probe:
-        trainer.allow_graph = False
-        for _ in range(150):  # the probe's own untimed steps (kernel set-up; ~40 ms of full load bring the chip to its
-                              # sustained clocks after the light reference-schedule region): its means feed `roofline_step`
-            trainer.epoch(dataset)
-        sync()
-        te = time.perf_counter()
-        with pkg.hip.Probe(launches_per_step * args.steps) as probe:
-            for _ in range(args.steps):
-                trainer.epoch(dataset)
-            sync()
-        eager_ms = 1e3 * (time.perf_counter() - te) / args.steps
-        for tag, ms in probe.records:
-            kernels.setdefault(tag, []).append(ms)
-    kmean = {k: float(np.mean(v)) for k, v in kernels.items()}
+        kmean, _by, eager_ms = probed(trainer, dataset, 150, args.steps)
 
     # third region (EVERY rank runs it: each step holds a collective when N > 1): the same step as
     # one kernel per operation -> timings of the stand-alone SpMM kernel
     spmm, k2 = [], {}
+    lib = pkg.hip.load()
     if args.mode == "batched" and not args.no_probe:
-        lib = pkg.hip.load()
         prev = lib.gmc_set_fuse(0)
-        for _ in range(10):
-            trainer.epoch(dataset)
-        with pkg.hip.Probe(launches_per_step * args.steps) as p2:
-            for _ in range(args.steps):
-                trainer.epoch(dataset)
-            sync()
+        _m, k2, _w = probed(trainer, dataset, 10, args.steps)
         lib.gmc_set_fuse(prev)
-        for tag, ms in p2.records:
-            k2.setdefault(tag, []).append(ms)
         spmm = [ms for tag in ("agg_fwd", "agg_bwd") for ms in k2.get(tag, [])]
+        note("probe + one-kernel-per-operation regions done")
+
+    # SpMM at several batch sizes ("config 3 must be reported at several batch sizes"):
+    # B = 1024 is the 160 graphs repeated (R = 1,024,000 rows, 4.1 GB per [R, F] operand: nothing can be cache-served)
+    by_batch = None
+    if not dp and args.mode == "batched" and not args.no_probe and not args.no_spmm_sweep and gpg >= 20:
+        by_batch = {}
+        keys = list(dataset)
+        prev = lib.gmc_set_fuse(0)
+        for B in (1, 20, min(160, gpg), 1024):
+            sub = {i: dataset[keys[i % len(keys)]] for i in range(B)}
+            net_b, embed_b, opt_b = fresh_model()
+            tr_b = T.FusedTrainer(net_b, opt_b, cfg, graphs_per_step=B, local_shard=True)
+            steps_b = 10 if B >= 1024 else 40
+            _m, kb, _w = probed(tr_b, sub, 5, steps_b)
+            durs = [ms for tag in ("agg_fwd", "agg_bwd") for ms in kb.get(tag, [])]
+            alg = tr_b._batches[0].spmm_bytes(tr_b.eng.Fp)
+            dur = float(np.mean(durs)) * 1e-3
+            by_batch[str(B)] = {"rows": tr_b._batches[0].R, "algorithmic_bytes_per_launch": alg, "mean_launch_us": dur * 1e6,
+                                "achieved_GBps": alg / dur / 1e9, "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
+                                "workgroups": tr_b._batches[0].B * lib_groups(pkg, tr_b._batches[0], tr_b.eng.Fp),
+                                "launches": len(durs)}
+            del tr_b, net_b, embed_b, opt_b, sub
+            torch.cuda.empty_cache()
+        lib.gmc_set_fuse(prev)
+        note("SpMM batch sweep done")
+
+    # the same step on other degrees / graph families (N = 1): a 7-slot specialisation must not be the only evidence
+    other = None
+    if extras_on:
+        other = {}
+        off = gpg
+        for name, kind, par, base, what in extra_defs:
+            gl = dict(enumerate(made[off:off + n_other]))
+            off += n_other
+            ds_o = extend(gl, {i: terminals_of(n, base + i) for i in gl})
+            net_o, embed_o, opt_o = fresh_model()
+            tr_o = T.FusedTrainer(net_o, opt_o, cfg, graphs_per_step=len(ds_o), local_shard=True)
+            k_o = max(20, args.steps // 2)
+            km_o, _by, _w = probed(tr_o, ds_o, 40, k_o)
+            dt_o, loss_o = timed(tr_o, ds_o, 20, k_o)
+            b0 = tr_o._batches[0]
+            other[name] = {
+                "workload": what, "ms_per_step": 1e3 * dt_o / k_o, "value": k_o * len(ds_o) / EPOCH_GRAPHS / dt_o,
+                "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)", "steps": k_o,
+                "kernels_us": {k: round(1e3 * v, 2) for k, v in sorted(km_o.items())},
+                "directed_edges": b0.nnz, "max_degree": b0.host.max_degree, "table_slots": b0.host.ell_width,
+                "live_slots": b0.host.ell_slots,
+                "overflow_blocks": int(b0.host.ovf_ptr[-1]) if b0.host.ovf_ptr is not None else 0,
+                "last_loss": loss_o, "parity": parity_gate(pkg, T, net_o, ds_o, n_graphs=1)}
+            net_o.train()
+            note(f"other workload {name} done")
+            del tr_o, net_o, embed_o, opt_o, ds_o, gl
+            torch.cuda.empty_cache()
+    del made
+
+    # data-parallel step sequence at the strong split's shard sizes, ONE rank over RCCL (N = 1 runs only)
+    dp_profile = None
+    if not dp and args.mode == "batched" and not args.no_dp_profile and not args.no_probe:
+        dp_profile = dp_shard_profile(args, pkg, T, cfg, dataset, fresh_model, timed, probed)
+        note("data-parallel shard profile done")
 
     trainer.allow_graph = True
 
-    # timed region: the step's launches are replayed hipGraphs (one per step on one GPU; forward/backward and
-    # Adam graphs around the eager all-reduce on N GPUs) - no per-launch host work
+    # timed region: eager launches queued behind the previous step's backward on one GPU (losses stored into pinned
+    # host memory); forward/backward and Adam around the eager all-reduce on N GPUs
     elapsed, last_loss = timed(trainer, dataset, args.warmup, args.steps)
+    note("headline timed region done")
 
     # N > 1, weak run: the same job on the strong split (160 graphs in total, 160 / N per rank)
     strong = None
@@ -274,14 +434,7 @@ def main():
     # per-step collective time (events on the launch stream around the eager all-reduce), N > 1
     allreduce_ms = None
     if dp:
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        sync()
-        for a, b in evs:
-            a.record()
-            eng.allreduce_grad()
-            b.record()
-        sync()
-        allreduce_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[2:]]))
+        allreduce_ms = allreduce_time_ms(eng, sync)
 
     if rank != 0:
         if dp:
@@ -315,9 +468,11 @@ def main():
                    "eager launches around the all-reduce (loss published to pinned host memory ahead of Adam)"
                    if dp and getattr(trainer, "_step_host_dev", None) else "eager"),
         "ms_per_step_eager_probed": eager_ms,
+        "host_enqueue_us_per_step": 1e6 * trainer.last_enqueue_s,
         "kernels_ms": {k: round(v, 5) for k, v in sorted(kmean.items())},
+        "graph_generation_s": round(t_gen, 2),
         "steady_state_note": "the first ~30 steps of a fresh process run ~9 % slower (clock ramp); the timed steps are the "
-                             "LAST region of this run (after the reference-schedule, probe and one-kernel-per-op regions), "
+                             "LAST region of this run (after the reference-schedule, probe, sweep and profile regions), "
                              "so they are sustained-clock steps at any --steps/--warmup; DESIGN.md quotes the defaults "
                              "--steps 200 --warmup 30",
     }
@@ -328,60 +483,175 @@ def main():
     if sequential is not None:
         out["sequential"] = sequential
 
-    # dominant kernels of the TIMED step on the bytes they must move (compulsory), PMC traffic beside them
-    R_, F_, N_ = gpg * n, args.hidden, 1000
-    chunks = 8
-    tfile_f = os.path.join(ROOT, "profiles", "traffic_fused.json")
-    traffic_f = json.load(open(tfile_f)) if os.path.exists(tfile_f) else {}
-    fused = {}
-    for tag, compulsory, what in (
-            ("fwd1_fused", R_ * F_ * 4 + N_ * F_ * 4 + R_ * 16 + R_ * 12 * 8,
-             "H write + W1 + neighbour table + 8 Zpart partials"),
-            ("bwd1_fused", R_ * F_ * 4 + R_ * 16 + R_ * 16 + chunks * N_ * F_ * 4,
-             "H read + (GY2, dinv) rows + neighbour table + 8 dW1 chunk partials")):
-        if tag in kmean:
-            dur = kmean[tag] * 1e-3
-            rec = traffic_f.get(tag) if traffic_f.get("rows") == R_ and traffic_f.get("F") == F_ else None
-            fused[tag] = {"kernel": {"fwd1_fused": "fwd1_lds_kernel", "bwd1_fused": "bwd1_reg_kernel"}[tag], "bound": "hbm",
-                          "achieved": compulsory / dur / 1e9,
-                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": compulsory / dur / 1e9 / HBM_PEAK_GBS,
-                          "traffic": rec, "compulsory_bytes_per_launch": compulsory, "compulsory_bytes_are": what,
-                          "mean_launch_us": dur * 1e6}
-    if fused:
-        dom = max(fused, key=lambda k: fused[k]["mean_launch_us"])
-        out["roofline_step"] = dict(fused[dom], also={k: v for k, v in fused.items() if k != dom})
-    else:
-        out["roofline_step"] = None
+    out["roofline"] = step_roofline(kmean, trainer._batches[0], eng, pkg) if kmean else None
 
     if k2:
         out["kernels_ms_unfused"] = {k: round(float(np.mean(v)), 5) for k, v in sorted(k2.items())}
     if spmm and args.mode == "batched":
         dur = float(np.mean(spmm)) * 1e-3
         achieved = spmm_bytes / dur / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_spmm.json")
-        if os.path.exists(tfile):
-            rec = json.load(open(tfile))
-            if rec.get("rows") == gpg * n and rec.get("F") == args.hidden:
-                traffic = rec.get("hbm_bytes_per_launch")
-        out["roofline"] = {
+        out["roofline_spmm"] = {
             "kernel": "spmm_lds_kernel (layer-1 aggregation SpMM, fwd + bwd launches; one-kernel-per-op leg)",
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic("traffic_spmm.json", "hbm_bytes_per_launch", gpg * n, eng.Fp),
             "algorithmic_bytes_per_launch": spmm_bytes, "mean_launch_us": dur * 1e6,
-            "launches": len(spmm),
+            "launches": len(spmm), "by_batch": by_batch,
         }
     else:
-        out["roofline"] = None
+        out["roofline_spmm"] = None
+    if other is not None:
+        out["other_workloads"] = other
+    if dp_profile is not None:
+        out["dp_shard_profile"] = dp_profile
 
     if not dp and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, graphs, terms, net)
-        if sequential is not None:   # same schedule on both sides: GPU reference-schedule rate / CPU rate
-            out["cpu_baseline"]["gpu_sequential_over_cpu"] = sequential["value"] / out["cpu_baseline"]["value"]
+        if sequential is not None:   # same schedule on both sides: GPU reference-schedule rate / CPU rate (both variants)
+            cb = out["cpu_baseline"]
+            cb["gpu_sequential_over_cpu"] = sequential["value"] / cb["value"]
+            cb["gpu_sequential_over_cpu_variant_B"] = sequential["value"] / cb["variants"]["B_sparse_c_1_thread"]["value"]
+            cb["ratio_note"] = ("reported baselines, not quality claims: the first ratio is against the reference-structured "
+                                "torch-CPU port at its best thread count, the second against the fastest CPU code in this "
+                                "line (scalar C, CSR, 1 thread)")
         out["parity"] = parity_gate(pkg, T, net, dataset)
     print(json.dumps(out), flush=True)
     if dp:
         dist.destroy_process_group()
+
+
+def lib_groups(pkg, batch, F):
+    """Workgroups per graph of the LDS-tiled SpMM for this batch (what decides how much of the chip a small batch uses)."""
+    slices = -(-F // 16)
+    per = 4
+    while per > 1 and batch.B * (-(-slices // per)) < 128:
+        per >>= 1
+    return -(-slices // per)
+
+
+def allreduce_time_ms(eng, sync, reps=20):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    sync()
+    for a, b in evs:
+        a.record()
+        eng.allreduce_grad()
+        b.record()
+    sync()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs[2:]]))
+
+
+def recorded_traffic(fname, key, rows, F):
+    """PMC traffic of a kernel from profiles/<fname> - only when that record was measured on THESE kernel sources
+    (its `csrc_sha` equals the fingerprint of gcn-max-cut_amd/csrc now) and on this shape; else None."""
+    path = os.path.join(ROOT, "profiles", fname)
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("rows") != rows or rec.get("F") != F or rec.get("csrc_sha") != csrc_fingerprint():
+        return None
+    return rec.get(key)
+
+
+def step_roofline(kmean, batch, eng, pkg):
+    """`roofline` of the line: the dominant kernel of the TIMED (default, fused) step - the fused layer-1 backward or
+    forward - on the bytes it must move, with the LDS line beside the HBM one."""
+    R_, F_, N_, nnz = batch.R, eng.Fp, eng.N, batch.nnz
+    B, W = batch.B, batch.host.ell_width
+    slices = -(-F_ // 16)
+    chunks = max(1, min(B, min(16, -(-256 // slices))))
+    zparts = lib_groups(pkg, batch, F_)
+    Fs = slices * 16
+    table = R_ * W * 2
+    fused = {}
+    defs = (
+        ("fwd1_fused", "fwd1_lds_kernel",
+         R_ * Fs * 4 + N_ * F_ * 4 + table + R_ * 4 + R_ * 12 * zparts,
+         f"H write + W1 + neighbour table + dinv + {zparts} Zpart partials",
+         # LDS: gather #1 + gather #2 reads, W1 tile landing + T0 tile writes
+         2 * nnz * Fs * 4 + 2 * R_ * Fs * 4),
+        ("bwd1_fused", "bwd1_reg_kernel" if W == 8 else "bwd1_lds_kernel",
+         R_ * Fs * 4 + R_ * 16 + table + chunks * batch.n_max * F_ * 4 + chunks * F_ * 16,
+         f"H read + (GY2, dinv) rows + neighbour table + {chunks} dW1 / column chunk partials",
+         # LDS: two gathers' reads, H tile landing + Gs in place (read + write) + U tile write
+         2 * nnz * Fs * 4 + 4 * R_ * Fs * 4))
+    for tag, kname, compulsory, what, lds_bytes in defs:
+        if tag not in kmean:
+            continue
+        dur = kmean[tag] * 1e-3
+        fused[tag] = {
+            "kernel": kname, "bound": "hbm", "achieved": compulsory / dur / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": compulsory / dur / 1e9 / HBM_PEAK_GBS,
+            "traffic": recorded_traffic("traffic_fused.json", tag, R_, F_),
+            "algorithmic_bytes_per_launch": compulsory, "algorithmic_bytes_are": what, "mean_launch_us": dur * 1e6,
+            "limited_by": "lds",
+            "lds": {"achieved": lds_bytes / dur / 1e9, "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                    "frac": lds_bytes / dur / 1e9 / LDS_PEAK_GBS, "bytes_per_launch": lds_bytes,
+                    "bytes_are": "ds_read_b128 of the two neighbour gathers (2 x directed edges x padded row of "
+                                 "F floats) + tile writes (DMA landing, in-place transform, gather #1 output)",
+                    "peak_is": "256 B/clk/CU x 256 CUs x 2.4 GHz (MI355X_MICROARCH.md, LDS); PMC: the array is busy "
+                               "59-72 % of wave time, a quarter of it bank conflicts (profiles/)"},
+            "in_timed_region": True}
+    if not fused:
+        return None
+    dom = max(fused, key=lambda k: fused[k]["mean_launch_us"])
+    return dict(fused[dom], also={k: v for k, v in fused.items() if k != dom})
+
+
+def dp_shard_profile(args, pkg, T, cfg, dataset, fresh_model, timed, probed):
+    """The data-parallel step (shard forward/backward -> all-reduce of [gradient | loss] -> publish -> Adam) on ONE
+    rank over RCCL at the shard sizes of the strong split of BASELINE configs[3] (160 graphs over 8 / 4 / 2 / 1 GPUs),
+    eager launches against GCN_MAXCUT_DP_GRAPHS=1.  Per-rank times are MEASURED; what N > 1 adds is the collective
+    between N ranks, which one GPU cannot measure (DESIGN section 7 carries the model)."""
+    import tempfile
+    keys = list(dataset)
+    saved = {k: os.environ.get(k) for k in ("GCN_MAXCUT_DP_SINGLE_RANK", "GCN_MAXCUT_DP_GRAPHS")}
+    store = tempfile.NamedTemporaryFile(prefix="gmc_dp_store_", delete=False)
+    store.close()
+    os.unlink(store.name)   # (FileStore wants to create it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = {"backend": None, "by_shard": {}}
+    try:
+        dist.init_process_group("nccl", init_method=f"file://{store.name}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", torch.cuda.current_device()))
+        out["backend"] = dist.get_backend()
+        os.environ["GCN_MAXCUT_DP_SINGLE_RANK"] = "1"
+        steps = max(20, min(args.steps, 100))
+        shards = [B for B in (20, 40, 80, 160) if B <= len(keys)] or [len(keys)]
+        for B in shards:
+            sub = {k: dataset[k] for k in keys[:B]}
+            rec = {}
+            for mode in ("eager", "graphs"):
+                os.environ["GCN_MAXCUT_DP_GRAPHS"] = "1" if mode == "graphs" else "0"
+                net_d, embed_d, opt_d = fresh_model()
+                tr = T.FusedTrainer(net_d, opt_d, cfg, graphs_per_step=B, local_shard=True)
+                assert tr.dp
+                dt, _ = timed(tr, sub, 20, steps)
+                host = []
+                for _ in range(20):
+                    tr.epoch(sub)
+                    host.append(tr.last_enqueue_s)
+                rec[mode] = {"ms_per_step": 1e3 * dt / steps, "host_enqueue_us": 1e6 * float(np.median(host))}
+                if mode == "eager":
+                    km, _by, _w = probed(tr, sub, 10, steps)
+                    rec["kernels_us"] = {k: round(1e3 * v, 2) for k, v in sorted(km.items())}
+                    rec["kernels_sum_us"] = round(1e3 * sum(km.values()), 2)
+                    torch.cuda.synchronize()
+                    rec["allreduce_single_rank_us"] = 1e3 * allreduce_time_ms(tr.eng, torch.cuda.synchronize)
+                del tr, net_d, embed_d, opt_d
+            rec["faster"] = min(("eager", "graphs"), key=lambda m: rec[m]["ms_per_step"])
+            out["by_shard"][str(B)] = rec
+        out["note"] = ("one rank over RCCL on one GPU: per-rank step time, kernel time, host enqueue time and the "
+                       "single-rank collective are measured; the N-rank all-reduce is not (see DESIGN section 7)")
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        with contextlib.suppress(OSError):
+            os.unlink(store.name)
+    return out
 
 
 def cpu_model_name() -> str:
@@ -461,14 +731,14 @@ def cpu_baseline(args, graphs, terms, net):
     }
 
 
-def parity_gate(pkg, T, net, dataset):
+def parity_gate(pkg, T, net, dataset, n_graphs=2):
     """Parity numbers reported with every perf number: probabilities
-    vs the C oracle on two graphs of the workload with the current weights."""
+    vs the C oracle on the first graphs of the workload with the current weights."""
     from oracle import c_oracle as CO
     params = {k: v.detach().cpu().numpy().copy() for k, v in net.state_dict().items()}
     worst, worst_unfused, arg_ok, loss_ok = 0.0, 0.0, True, True
     net.eval()
-    for key in list(dataset)[:2]:
+    for key in list(dataset)[:n_graphs]:
         g, a_pad, nx_g, _t = dataset[key]
         with torch.no_grad():
             P = net(g, a_pad).cpu().numpy()

@@ -18,10 +18,11 @@ RCCL all-reduce of the flat gradient per step.
 from __future__ import annotations
 
 import os
+import warnings
 import random  # noqa: F401  (reference namespace)
 from dataclasses import dataclass
 from itertools import chain, permutations
-from time import time
+from time import perf_counter, sleep, time
 from typing import Callable, Dict, List, Optional, Tuple  # noqa: F401
 
 import numpy as np
@@ -32,7 +33,7 @@ import torch.nn.functional as F  # noqa: F401
 
 from .. import hip
 from ..commons import open_file, save_object  # noqa: F401
-from ..engine import PARAM_ORDER, FusedEngine, dp_active, shard_for_rank
+from ..engine import PARAM_ORDER, FusedEngine, dp_active, shard_by_weight, shard_for_rank  # noqa: F401
 from ..graph import GraphBatch, GraphHandle
 
 TORCH_DEVICE = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
@@ -315,6 +316,11 @@ def _graphs_per_step(explicit: Optional[int]) -> int:
     return max(1, int(os.environ.get("GCN_MAXCUT_GRAPHS_PER_STEP", "1")))
 
 
+_NOT_LANDED = np.uint32(0x7FC0DEAD)   # quiet-NaN payload no arithmetic produces: "this loss slot has not been written"
+_SPIN_BEFORE_YIELD = 2048             # ~0.5 ms of looks before the polling loops start yielding the core
+_POLL_DEADLINE_S = 5.0
+
+
 class FusedTrainer:
     """Device-resident state of one (model, optimizer) pair: per-step graph batches, loss
     slots, and the bridge that exposes the fused Adam moments through the torch optimizer
@@ -352,15 +358,32 @@ class FusedTrainer:
         self._loss_host: Optional[torch.Tensor] = None
         self._step_host: Optional[torch.Tensor] = None
         self._out = None
+        self.last_enqueue_s = 0.0
+        self.deadline_hits = 0      # epochs whose losses did not land within the polling deadline (see _wait_for_losses)
+
+    def invalidate(self) -> None:
+        """Forget the planned batches (and the captured hipGraphs with them): the next epoch walks the dataset
+        again.  Call it after editing a dataset dict in a way :meth:`prepare` cannot see (see there)."""
+        self._plan_key = None
+        self._graph = None
+        self._dp_graph = None
 
     def prepare(self, dataset: Dict) -> None:
-        # O(1) per epoch: the dict, its size, and its first / last items by identity + in-place version of their
-        # adjacency (an item replaced or edited in place re-plans; the full walk happens only then)
+        """Plan the device batches for ``dataset`` once and keep them while it is the same dataset.  "The same" is
+        decided cheaply per epoch (the reference re-reads ``dataset.items()`` every epoch, TrainingNeural.py:371; a
+        full walk per 0.2 ms step would cost more than the step): the dict object and its length, plus - for every
+        item of a small dataset (<= 32 items), else for the first, the last and six evenly spaced items - the
+        identity of the graph handle and of the adjacency tensor and the tensor's in-place version counter.
+        Replacing or editing an item those probes miss needs :meth:`invalidate`."""
         probe = None
         if dataset:
-            first = next(iter(dataset.values()))
-            last = dataset[next(reversed(dataset))] if hasattr(dataset, "__reversed__") else first
-            probe = tuple((id(it[0]), id(it[1]), getattr(it[1], "_version", 0)) for it in (first, last))
+            n_items = len(dataset)
+            if n_items <= 32 or not hasattr(dataset, "__reversed__"):
+                picked = list(dataset.values()) if n_items <= 32 else [next(iter(dataset.values()))]
+            else:
+                keys = list(dataset)   # (a list of 160 ints: ~1 us)
+                picked = [dataset[keys[(n_items - 1) * j // 7]] for j in range(8)]
+            probe = tuple((id(it[0]), id(it[1]), getattr(it[1], "_version", 0)) for it in picked)
         key = (id(dataset), len(dataset), self.graphs_per_step, self.world, probe)
         if key == self._plan_key:
             return
@@ -370,7 +393,9 @@ class FusedTrainer:
         stride = gps if self.local_shard else gps * self.world
         for start in range(0, len(items), stride):
             group = items[start:start + stride]
-            mine = group if self.local_shard else [group[i] for i in shard_for_rank(len(group), self.rank, self.world)]
+            # this rank's contiguous share of the group, balanced by directed edges (== by count for equal graphs)
+            mine = group if self.local_shard else [group[i] for i in shard_by_weight(
+                [it[0].number_of_edges() for it in group], self.rank, self.world)]
             handles = [it[0] for it in mine]
             vals = [h.edge_values(it[1]) for h, it in zip(handles, mine)]
             self._batches.append(self.eng.make_batch(handles, vals))
@@ -385,6 +410,7 @@ class FusedTrainer:
         self._loss_host = (torch.empty_like(self._loss_slots, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         self._loss_host_np = self._loss_host.numpy() if self._loss_host is not None else None   # (shares the pinned memory)
+        self._loss_host_bits = self._loss_host_np.view(np.uint32) if self._loss_host_np is not None else None
         # device-side address of that pinned buffer: the captured steps store their per-graph losses straight
         # into it (one system-scope store each, as soon as the value is final), so the host has a step's loss
         # while its backward is still running and no copy node trails the graph (GCN_MAXCUT_LOSS_ZEROCOPY=0: copy)
@@ -395,6 +421,7 @@ class FusedTrainer:
         self._step_host = (torch.empty_like(self._step_loss, device="cpu").pin_memory()
                            if dev.type == "cuda" else None)
         self._step_host_np = self._step_host.numpy() if self._step_host is not None else None
+        self._step_host_bits = self._step_host_np.view(np.uint32) if self._step_host_np is not None else None
         # data-parallel steps: the all-reduced loss of a step (the gradient's tail slot) is published to this pinned
         # buffer by a one-wave launch BEFORE the step's Adam launches, so the host has it while Adam still runs
         self._step_host_dev = None
@@ -432,6 +459,7 @@ class FusedTrainer:
 
     def epoch(self, dataset: Dict) -> float:
         """One pass over the dataset; returns the cumulative loss (one host sync)."""
+        t_entry = perf_counter()
         self.prepare(dataset)
         eng, cfg = self.eng, self.config
         drop = self._dropout()
@@ -460,7 +488,7 @@ class FusedTrainer:
                         and getattr(self, "_loss_host_dev", None) is not None)
         poll = (use_graph or eager_direct) and self._poll and self._loss_host_np is not None
         if poll:
-            self._loss_host_np.fill(np.nan)   # sentinel: every loss is a finite number (<= 0)
+            self._loss_host_bits.fill(_NOT_LANDED)   # sentinel bit pattern: no kernel produces it, a NaN LOSS is not it
         if use_graph:
             self._replay_epoch()
         elif not self.dp and hasattr(eng, "train_step"):
@@ -479,7 +507,7 @@ class FusedTrainer:
                     eng.ensure_slab()   # (a launch only when torch wrote the parameters since the last step)
             publish = self._step_host_dev if self.dp else None
             if publish:
-                self._step_host_np.fill(np.nan)   # sentinel: every step loss is a finite number
+                self._step_host_bits.fill(_NOT_LANDED)   # sentinel bit pattern (a NaN loss is a landed value)
             for i, batch in enumerate(self._batches):
                 if batch.B == 0:
                     # this rank's shard of the step is empty (last group smaller than the world): it
@@ -491,9 +519,12 @@ class FusedTrainer:
                 else:
                     eng.train_fwd_bwd(batch, cfg.C, out=(self._out[0], self._out[1], self._loss_slots[i]),
                                       **({"ws": self._ws} if self._ws is not None else {}), **self._slab)
+                fused_publish = None
                 if self.dp:
                     eng.allreduce_grad()               # ONE RCCL all-reduce of [gradient | loss] per step, eager
-                    if publish:                        # the step's loss -> pinned host slot i, ahead of Adam
+                    if publish and graphs is None and self._slab and hasattr(eng, "adam_step_dev"):
+                        fused_publish = (tail, publish + 4 * i)   # rides in front of the Adam launch below
+                    elif publish:                      # the step's loss -> pinned host slot i, ahead of Adam
                         eng.publish(tail, publish + 4 * i)
                     elif i != last:                    # the last step's slot is read in place below
                         self._step_loss[i:i + 1].copy_(tail)
@@ -503,16 +534,18 @@ class FusedTrainer:
                     eng._dev_step += 1
                 elif self._slab and hasattr(eng, "adam_step_dev"):
                     eng.sync_step_dev()                # (a launch only after host-stepped updates)
-                    eng.adam_step_dev(lr, betas, eps, **self._slab)   # keeps the slab copy of W1 current
+                    # keeps the slab copy of W1 current; with `publish`: loss store + counter tick + Adam in two launches
+                    eng.adam_step_dev(lr, betas, eps, **self._slab, **({"publish": fused_publish} if fused_publish else {}))
                 else:
                     eng.adam_step(lr, betas, eps)
+        self.last_enqueue_s = perf_counter() - t_entry   # host time to queue the epoch's launches (bench.py reports it)
         if self.dp:   # one host sync per epoch
             if not self._batches:
                 return 0.0
             if self._step_host is not None:
-                host = self._step_host_np
+                host, bits = self._step_host_np, self._step_host_bits
                 if self._poll and not publish:
-                    host.fill(np.nan)   # sentinel: every step loss is a finite number
+                    bits.fill(_NOT_LANDED)   # sentinel bit pattern (a NaN loss is a landed value)
                 if publish:
                     pass            # every step has already sent its loss
                 elif last == 0:   # one step per epoch: its loss goes from the gradient's tail slot to the host
@@ -523,16 +556,16 @@ class FusedTrainer:
                 if self._poll:   # watch the pinned slots instead of sleeping in the stream sync (see _wait_for_losses)
                     spins, deadline = 0, None
                     while True:
-                        total = float(host.sum(dtype=np.float64))
-                        if total == total:
-                            return total
+                        if bits[last] != _NOT_LANDED and not (bits == _NOT_LANDED).any():
+                            return float(host.sum(dtype=np.float64))
                         spins += 1
-                        if spins & 0xFFF == 0:
+                        if spins > _SPIN_BEFORE_YIELD and spins & 63 == 0:
+                            sleep(0)   # give the core away: RCCL's proxy threads and the other ranks' hosts share it
                             now = time()
-                            deadline = deadline or now + 5.0
-                            if now > deadline:   # stream done after this: a NaN that is still there is the result
-                                torch.cuda.current_stream().synchronize()
-                                return float(host.sum(dtype=np.float64))
+                            deadline = deadline or now + _POLL_DEADLINE_S
+                            if now > deadline:
+                                self._deadline_hit()
+                                break
                 torch.cuda.current_stream().synchronize()
                 return float(host.sum(dtype=np.float64))
             self._step_loss[last:last + 1].copy_(tail)
@@ -556,33 +589,45 @@ class FusedTrainer:
         return total
 
     def _wait_for_losses(self, host: np.ndarray) -> float:
-        """The replayed graph ends with the copy of the per-graph losses into pinned host memory: the host
-        watches that memory instead of sleeping in hipStreamSynchronize (whose wake-up costs ~10 us per step
-        of a 0.25 ms step).  The slots were filled with NaN before the launch; a step's sum is taken once
-        its first and last slot have landed and is accepted when it is a number (a slot still missing makes
-        it NaN).  A sentinel that does not go away within seconds hands over to the stream synchronisation,
-        which reports whatever went wrong on the device.  Returns the epoch's cumulative loss."""
+        """The loss kernels store every graph's loss straight into pinned host memory (or the replayed graph ends
+        with that copy): the host watches that memory instead of sleeping in hipStreamSynchronize (whose wake-up
+        costs ~10 us per step of a 0.25 ms step).  "Not landed yet" is a BIT PATTERN (`_NOT_LANDED`, a NaN payload
+        no kernel produces) the slots are filled with before the launch, so a loss that genuinely IS NaN (diverged
+        weights) counts as landed and comes back as NaN at once - as `loss.item()` would (TrainingNeural.py:387-388).
+        After ~0.5 ms of spinning the loop yields the core between looks; slots that have not landed within
+        `_POLL_DEADLINE_S` hand over to the stream synchronisation - which reports whatever went wrong on the device -
+        and polling is switched off for the rest of the run with ONE warning (e.g. pinned memory that is not
+        host-coherent: every epoch would otherwise pay the deadline).  Returns the epoch's cumulative loss."""
+        bits = self._loss_host_bits
         total, deadline = 0.0, None
         for i, batch in enumerate(self._batches):
             nb = batch.B
             if nb == 0:
                 continue
-            row, spins = host[i], 0
+            row, brow, spins = host[i], bits[i], 0
             while True:
-                if row[nb - 1] == row[nb - 1] and row[0] == row[0]:      # (x == x: not NaN)
-                    step = float(row[:nb].sum(dtype=np.float32))
-                    if step == step:
-                        total += step
-                        break
+                if brow[nb - 1] != _NOT_LANDED and brow[0] != _NOT_LANDED and not (brow[:nb] == _NOT_LANDED).any():
+                    total += float(row[:nb].sum(dtype=np.float32))
+                    break
                 spins += 1
-                if spins & 0xFFF == 0:
+                if spins > _SPIN_BEFORE_YIELD and spins & 63 == 0:
+                    sleep(0)
                     now = time()
-                    deadline = deadline or now + 5.0
+                    deadline = deadline or now + _POLL_DEADLINE_S
                     if now > deadline:   # the stream is done after this: whatever the slots hold IS the result
                         torch.cuda.current_stream().synchronize()   # (raises if the device faulted)
+                        self._deadline_hit()
                         total += float(row[:nb].sum(dtype=np.float32))
                         break
         return total
+
+    def _deadline_hit(self) -> None:
+        self.deadline_hits += 1
+        if self._poll:
+            self._poll = False
+            warnings.warn("GCN max-cut: the step's losses did not reach the pinned host buffer within "
+                          f"{_POLL_DEADLINE_S:.0f} s of polling; falling back to stream synchronisation for the rest "
+                          "of this run (is the pinned memory host-coherent? HIP_HOST_COHERENT=0 breaks zero-copy stores)")
 
     def _use_graph(self) -> bool:
         """On one GPU an epoch's launches (the reference's one Adam step per graph: hundreds of
@@ -703,7 +748,9 @@ def _trainer_for(net, optimizer, config, graphs_per_step: Optional[int] = None) 
 def train_single_epoch(dataset: Dict, net, optimizer, embed, config: TrainingConfig,
                        dataset_files: Optional[List[str]] = None, *,
                        graphs_per_step: Optional[int] = None) -> float:
-    """One epoch, cumulative loss (TrainingNeural.py:341-390)."""
+    """One epoch, cumulative loss (TrainingNeural.py:341-390).  The device batches planned for ``dataset`` are
+    kept from epoch to epoch while it looks unchanged (:meth:`FusedTrainer.prepare` says how that is decided);
+    after editing a large dataset dict in place call ``net._fused_trainer.invalidate()``."""
     net.train()
     trainer = _trainer_for(net, optimizer, config, graphs_per_step)
     if dataset_files is None:

@@ -10,7 +10,7 @@ directory on ``sys.path`` to get the reference's own import roots
 """
 from . import hip  # noqa: F401
 from .graph import BatchArrays, DGLError, GraphBatch, GraphHandle, from_networkx  # noqa: F401
-from .engine import FusedEngine, shard_for_rank  # noqa: F401
+from .engine import FusedEngine, shard_by_weight, shard_for_rank  # noqa: F401
 
 __version__ = "0.1.0"
 

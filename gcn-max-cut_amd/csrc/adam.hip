@@ -56,12 +56,13 @@ struct AdamDevArgs {
     const int *step_counter;
     float *w1_slab;  // optional: slab copy of the first N*F parameters (conv1.weight), refreshed with the update
     int N, F;
+    int step_bias;   // 1: *step_counter = steps done so far (this launch applies step + 1); 0: it already holds this step's number
 };
 
 __global__ __launch_bounds__(256) void adam_devstep_kernel(AdamDevArgs d) {
     __shared__ float sh[2];
     if (threadIdx.x == 0) {
-        const double t = (double)(*d.step_counter + 1);
+        const double t = (double)(*d.step_counter + d.step_bias);
         const double bc1 = 1.0 - pow(d.beta1, t), bc2 = 1.0 - pow(d.beta2, t);
         sh[0] = (float)(d.lr / bc1);
         sh[1] = (float)sqrt(bc2);
@@ -94,18 +95,32 @@ __global__ __launch_bounds__(256) void adam_devstep_kernel(AdamDevArgs d) {
 
 __global__ void adam_tick_kernel(int *step_counter) { *step_counter += 1; }
 
+// one wave in front of a data-parallel rank's Adam launch: hands the step's (all-reduced) loss to the host - one
+// system-scope store per value into pinned memory - and advances the step counter, so that the Adam launch behind it
+// uses the counter as it stands and no one-thread launch has to trail it
+__global__ __launch_bounds__(64) void publish_tick_kernel(const float *src, int n, float *dst, int *step_counter) {
+    for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) *step_counter += 1;
+}
+
 }  // namespace
 
 namespace {
 int adam_devstep(float *param, const float *grad, float *m, float *v, int64_t count, double lr, double beta1,
-                 double beta2, double eps, int32_t *step_counter, gmc_stream_t stream, float *w1_slab, int N, int F) {
+                 double beta2, double eps, int32_t *step_counter, gmc_stream_t stream, float *w1_slab, int N, int F,
+                 const float *publish_src = nullptr, int publish_n = 0, float *publish_dst = nullptr) {
     if (!param || !grad || !m || !v || !step_counter) return GMC_ERR_NULL;
     if (count < 0) return GMC_ERR_SHAPE;
     if (!gmc_aligned16(param) || !gmc_aligned16(grad) || !gmc_aligned16(m) || !gmc_aligned16(v))
         return GMC_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool ticked = publish_dst != nullptr;   // publish + tick first, then Adam with the counter as it stands
+    if (ticked) {
+        hipLaunchKernelGGL(publish_tick_kernel, dim3(1), dim3(64), 0, st, publish_src, publish_n, publish_dst, step_counter);
+        GMC_LAUNCH_CHECK();
+    }
     if (count > 0) {
-        AdamDevArgs d{param, grad, m, v, (long)count, lr, beta1, beta2, (float)eps, step_counter, w1_slab, N, F};
+        AdamDevArgs d{param, grad, m, v, (long)count, lr, beta1, beta2, (float)eps, step_counter, w1_slab, N, F, ticked ? 0 : 1};
         long blocks = ((count >> 2) + 255) / 256;
         if (blocks < 1) blocks = 1;
         if (blocks > 2048) blocks = 2048;
@@ -113,8 +128,10 @@ int adam_devstep(float *param, const float *grad, float *m, float *v, int64_t co
         hipLaunchKernelGGL(adam_devstep_kernel, dim3((int)blocks), dim3(256), 0, st, d);
         GMC_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
-    GMC_LAUNCH_CHECK();
+    if (!ticked) {
+        hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step_counter);
+        GMC_LAUNCH_CHECK();
+    }
     return GMC_OK;
 }
 }  // namespace
@@ -134,6 +151,21 @@ extern "C" int gmc_adam_devstep_model_f32(float *param, const float *grad, float
     if (w1_slab && !gmc_aligned16(w1_slab)) return GMC_ERR_ALIGN;
     const int64_t count = (int64_t)N * F + F + (int64_t)F * 3 + 3;
     return adam_devstep(param, grad, m, v, count, lr, beta1, beta2, eps, step_counter, stream, w1_slab, N, F);
+}
+
+// the data-parallel rank's tail of a step in two launches: (1) one wave stores `publish_n` floats from `publish_src`
+// (the all-reduced loss: the slot after the gradient) into pinned host memory and advances the step counter;
+// (2) gmc_adam_devstep_model_f32's sweep with the counter as it then stands
+extern "C" int gmc_publish_adam_devstep_model_f32(const float *publish_src, int32_t publish_n, float *pinned_dst, float *param,
+                                                  const float *grad, float *m, float *v, int32_t N, int32_t F, float *w1_slab,
+                                                  double lr, double beta1, double beta2, double eps, int32_t *step_counter,
+                                                  gmc_stream_t stream) {
+    if (!publish_src || !pinned_dst) return GMC_ERR_NULL;
+    if (N <= 0 || F <= 0 || F % 4 || publish_n < 1) return GMC_ERR_SHAPE;
+    if (w1_slab && !gmc_aligned16(w1_slab)) return GMC_ERR_ALIGN;
+    const int64_t count = (int64_t)N * F + F + (int64_t)F * 3 + 3;
+    return adam_devstep(param, grad, m, v, count, lr, beta1, beta2, eps, step_counter, stream, w1_slab, N, F, publish_src,
+                        publish_n, pinned_dst);
 }
 
 extern "C" int gmc_adam_f32(float *param, const float *grad, float *m, float *v, int64_t count,

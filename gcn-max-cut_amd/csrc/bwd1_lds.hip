@@ -31,6 +31,8 @@ struct Bwd1Args {
     int slices;
     int chunks;
     int graphs_per_chunk;
+    int ovf_cap;          // OVF kernels: overflow blocks that fit into the LDS behind the kernel's regions ...
+    int own_lds;          // ... which end at this byte offset
 };
 
 // per-thread state shared by the two kernel flavours: my 4 columns as two pairs p = (f0+2p, f0+2p+1) -
@@ -58,9 +60,9 @@ __device__ __forceinline__ void col_state_init(ColState &c, const float *W2, int
 // row's dW2 / db1 terms.  rck = (GY2[r,0..2], dinv[r]).  Pad columns need no masks (their W2 rows are 0
 // here and the H slab holds exact zeros there); rows past n work on the zero row (h = 0 -> Gs = 0,
 // partials += 0): no exec masks either.
-__device__ __forceinline__ void transform_row(ColState &c, float4 *cell, const float4 rck) {
+__device__ __forceinline__ void transform_row(ColState &c, float4 *cell, const float4 rck, const float4 *hreg = nullptr) {
     const float d = rck.w;
-    const float4 h = *cell;
+    const float4 h = hreg ? *hreg : *cell;   // (hreg: the cell's H values are already in registers)
     const gmc::v2f g0 = gmc::splat2(rck.x * d), g1 = gmc::splat2(rck.y * d), g2 = gmc::splat2(rck.z * d);
     const gmc::v2f hp[2] = {{h.x, h.y}, {h.z, h.w}};
     gmc::v2f gs[2];
@@ -133,16 +135,18 @@ __device__ __forceinline__ void dma_row_consts(const float *GY2, int r0, int n, 
 
 // ---- 8-slot tables (degree <= 8: every reference configuration) -------------------------------------
 // A thread's rows' neighbour ids live in registers for the whole graph (both gathers): no table in LDS.
-// Two barriers per graph:
-//     transform(g) [own cells]  -> A ->  gather #1 (bufA -> bufB)  -> B ->  DMA(g+1) -> bufA || gather #2
-// (the 16-slot flavour below needs three: its table lives in the LDS the second constants buffer uses)
+// Two barriers per graph; the transform of graph g+1 follows gather #2 of graph g in the same barrier interval:
+//     -> A ->  gather #1(g) (bufA -> bufB)  -> B ->  DMA(g+1) -> bufA || gather #2(g), then transform(g+1)
+// (the 16-slot flavour below needs more: its table lives in the LDS the second constants buffer uses)
 // * a thread transforms exactly the cells its own DMA instructions fetched, so the H tile of graph g+1
-//   needs no rendezvous between "landed" (the issuing wave's vmcnt) and the transform;
+//   needs no rendezvous between "landed" (the issuing wave's vmcnt) and the transform.  The loop can also
+//   interleave the transform of piece k (counted vmcnt: pieces retire in issue order) with the rows of gather #2
+//   (tuning builds, GMC_BWD1_LEAD) - measured, no gain, see the note at kLead.
 // * the row constants are double-buffered (the second buffer is the LDS the 16-slot flavour keeps its
-//   table in) and fetched a graph ahead, between A and B, so barrier B publishes them;
+//   table in) and fetched a graph ahead, between A and B, so barrier B publishes them before transform(g+1);
 //   (Tried and dropped, measured same-box: pulling the H tile of graph g+2 into L2 with 4-byte LDS-DMA
 //   touches while the tile of g+1 streams in, so that the DMA runs at L2 latency - the kernel got 11 %
-//   SLOWER; the tile DMA's only shadow stays gather #2.)
+//   SLOWER.)
 template <int FS, int ACC, bool HAS_VAL, int NS, bool OVF>
 __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -170,11 +174,44 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     const int g0 = chunk * a.graphs_per_chunk, g1 = min(a.b.B, g0 + a.graphs_per_chunk);
     if (g0 >= g1) return;
     constexpr bool ovf = OVF;   // some row of the batch has more than 8 neighbours: overflow lists (gmc_batch.ovf_*)
+    // first row of my wave in pass 0 (wave-uniform): pass k of the tile DMA is issued by this wave iff that row + k *
+    // rows-per-pass is a row of the graph - what the counted waits below have to know
+    const int wrow0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u) / Q);
 
+    // KREG of my ACC cells of the next graph's H tile do not come by LDS-DMA after barrier B but by ordinary loads
+    // into registers issued a phase EARLIER (behind barrier A, while bufA is still being gathered from): their
+    // shadow is gather #1 + gather #2, and the DMA that is left moves (ACC - KREG) / ACC of the tile in gather #2's
+    // shadow.  Every wave issues exactly KREG such loads per graph (rows past n re-read row n-1): the wait for the
+    // row constants' DMA in front of barrier B counts on it.
+    // Measured (round 3, same box, R = 160,000, us per launch): KREG 0: 112.4-114.7 | 1: 113.8-114.0 | 2: 111.7-112.6 |
+    // 3: 110.9-111.6.  Worth 1-2 %: the tile's arrival is not what the loop waits for most.
+#ifndef GMC_BWD1_KREG
+#define GMC_BWD1_KREG 3
+#endif
+    constexpr int KREG = (!HAS_VAL && !OVF) ? (GMC_BWD1_KREG < ACC ? GMC_BWD1_KREG : ACC) : 0;
+    float4 hreg[KREG > 0 ? KREG : 1];
+    auto load_hreg = [&](int r0n, int nn) {
+#pragma unroll
+        for (int k = 0; k < KREG; ++k) {
+            const int l = min(lrow + k * kRowsPerPass, nn - 1);
+            const gmc::v4f v = __builtin_nontemporal_load(reinterpret_cast<const gmc::v4f *>(Hs + (long)(r0n + l) * FS + 4 * q));
+            hreg[k] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
     uint4 idr[ACC];
+    // overflow lists (OVF): my rows' (start, count) travel with the ids; the graph's first blocks sit in the spare
+    // LDS, in the half `parity` of it (the next graph's are written while this graph's are still being read)
+    int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
+    uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
+    const int ocap = a.ovf_cap / 2;
+    auto ovf_of = [&](int r0, int parity) {
+        const int ob = a.b.ovf_ptr[r0];
+        return OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr,
+                        ovl + parity * ocap, ocap};
+    };
     // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
     // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
-    auto load_ids = [&](int r0, int n) {
+    auto load_ids = [&](int r0, int n, int parity) {
         const unsigned pad = (unsigned)n * 0x10001u;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -182,81 +219,151 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             const uint4 v = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(l, n - 1)) * W);
             idr[k] = l < n ? v : make_uint4(pad, pad, pad, pad);
         }
+        if constexpr (ovf) {
+            const int ob = a.b.ovf_ptr[r0];
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, lrow + k * kRowsPerPass, ob, ostart[k], ocnt[k]);
+            ovf_stage(ovf_of(r0, parity), ovl + parity * ocap, a.b.ovf_ptr[r0 + n] - ob);
+        }
     };
     auto zero_pads = [&](float *buf, int n) {  // the zero rows n..n+3 the padding entries point at
         if (threadIdx.x < kPadRows * FS) buf[n * FS + threadIdx.x] = 0.f;
     };
-    auto fetch_tile = [&](int r0, int n) {  // H tile of the graph at rows [r0, r0+n) -> bufA
-        dma_tile<FS, ACC, true>(Hs + (long)r0 * FS + 4 * q, FS, n, true, lrow, bufA);   // H: read once
+    auto fetch_tile = [&](int r0, int n, int k0) {  // H tile of the graph at rows [r0, r0+n) -> bufA, my passes k0..ACC-1
+        constexpr int kRows = kThreads / (FS / 4);
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)bufA;
+        const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (threadIdx.x & ~63u)));
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) {
+            const int l = lrow + k * kRows;
+            if (k >= k0 && l < n) glds16<true>(Hs + (long)(r0 + l) * FS + 4 * q, wave_dst + 16u * (unsigned)(k * kThreads));   // H: read once
+        }
+    };
+    // H -> Gs for my cell of pass k of a graph of n rows (row constants from `gyl`).  Rows past n: constants 0 make
+    // Gs = 0 and add 0 to the partials whatever (finite) bytes the cell holds - no exec mask, and no dependence on
+    // when another wave zeroed the padding rows.
+    auto transform = [&](int k, int n, const float *gyl) {
+        if (ABL(7)) return;
+        const int l = lrow + k * kRowsPerPass;
+        float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
+        if (l >= n) rck = gmc::f4_zero();
+        transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck, k < KREG ? &hreg[k] : nullptr);
+    };
+    // wait until piece k of the tile DMA this wave issued `pieces` pieces of has landed (they retire in issue order;
+    // younger loads of the gather only make the wait longer than needed, never shorter)
+    auto wait_piece = [&](int k, int pieces) {
+        const int younger = pieces - 1 - k;   // wave-uniform
+#if defined(GMC_BWD1_FULLWAIT) || !defined(GMC_BWD1_LEAD)   // default: the whole tile before the first transform
+        dma_wait();
+        return;
+#endif
+        if (younger <= 0) dma_wait();
+        else if (younger == 1) vm_wait<1>();
+        else if (younger == 2) vm_wait<2>();
+        else if (younger == 3) vm_wait<3>();
+        else if (younger == 4) vm_wait<4>();
+        else if (younger == 5) vm_wait<5>();
+        else if (younger == 6) vm_wait<6>();
+        else vm_wait<7>();
     };
 
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     int nn = g0 + 1 < g1 ? a.b.goff[g0 + 2] - (r0 + n) : 0;   // size of graph g+1 (0: none)
     dma_row_consts(a.GY2, r0, n, gy0);
-    fetch_tile(r0, n);
-    load_ids(r0, n);
+    fetch_tile(r0, n, KREG);
+    load_hreg(r0, n);
+    load_ids(r0, n, 0);
     zero_pads(bufA, n);
     dma_wait();
     __syncthreads();
     STAMP_DECL;
     MARK(1);
+#pragma unroll
+    for (int k = 0; k < ACC; ++k) transform(k, n, gy0);   // first graph: nothing to hide behind
     for (int g = g0; g < g1; ++g) {
         const int cur = (g - g0) & 1;
         const float *gyl = cur ? gy1 : gy0;
+        float *gyn = cur ? gy0 : gy1;
+        OvfGraph og{};
+        if constexpr (ovf) og = ovf_of(r0, cur);
         const int r0n = r0 + n;                                              // == goff[g + 1]
         const int n2 = g + 2 < g1 ? a.b.goff[g + 3] - (r0n + nn) : 0;        // size of graph g+2 (0: none)
-        float dv[ACC];
         STAMP(0);
-        // (1) my own cells of the H tile (landed: waited for below / in the prologue) -> Gs
-#pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            const float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
-            dv[k] = rck.w;
-            if (ABL(7)) continue;
-            transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck);
-        }
-        // row constants of graph g+1 into the other buffer: published by barrier B
-        if (nn > 0 && !ABL(1)) dma_row_consts(a.GY2, r0n, nn, cur ? gy0 : gy1);
-        STAMP(1);  // transform
+        // row constants of graph g+1 into the other buffer (its last reader, transform(g-1), is two barriers back):
+        // published by barrier B, read by transform(g+1) behind it
+        if (nn > 0 && !ABL(1)) dma_row_consts(a.GY2, r0n, nn, gyn);
+        STAMP(1);
         loop_barrier();
-        STAMP(2);  // barrier A: every Gs cell is written; every wave is done with gather #2 of graph g-1
+        STAMP(2);  // barrier A: every Gs cell of graph g is written; every wave is done with gather #2 of graph g-1
+        // (the transforms of graph g are done with hreg.  Unconditional - the last graph re-reads rows of its own -
+        // so that every path issues the same number of loads: a branch here makes the compiler wait for vmcnt(0)
+        // at the join, i.e. for these very loads, before the first gather read)
+        if (KREG > 0) load_hreg(nn > 0 ? r0n : r0, nn > 0 ? nn : n);
         // (2) U tile = dinv o (A @ Gs)
         zero_pads(bufB, n);
+        float dv[ACC];
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) dv[k] = gyl[4 * min(lrow + k * kRowsPerPass, n - 1) + 3];
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
             float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
-            if (ovf && l < n) gmc::f4_add(u, gather_overflow<FS, false>(bufA, a.b, r0 + l, q));   // hub rows: their own extra blocks
+            if constexpr (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, og, ostart[k], ocnt[k], q));   // hub rows: their own extra blocks
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
         }
         STAMP(3);  // gather 1
-        dma_wait();   // my share of graph g+1's row constants
+        // my share of graph g+1's row constants (the KREG register loads behind it may stay in flight)
+        if (KREG > 0) vm_wait<KREG>();
+        else dma_wait();
         loop_barrier();
         STAMP(4);  // barrier B: U tile complete, bufA free, next row constants visible
-        // (3) next graph's H tile streams into bufA while (4) gathers from bufB
+        // (3) next graph's H tile streams into bufA while (4) gathers from bufB and (1') turns the landed pieces into Gs
+        int pieces = 0;   // tile DMA instructions this wave issues for graph g+1 (wave-uniform)
         if (nn > 0 && !ABL(1)) {
-            fetch_tile(r0n, nn);
+            fetch_tile(r0n, nn, KREG);
             zero_pads(bufA, nn);
+#pragma unroll
+            for (int k = KREG; k < ACC; ++k) pieces += wrow0 + k * kRowsPerPass < nn ? 1 : 0;
         }
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
+        // order inside a wave: the first half of gather #2 goes ahead of the first transform (the DMA needs about
+        // that long), then they alternate; across waves nothing is in step any more - one wave's packed-FMA
+        // transform runs beside the others' LDS reads
+        // Measured (round 3, same box, us per launch at R = 160,000): transform after the whole gather and a full wait
+        // 112.2-113.1 | lead ACC with counted waits 113.1-114.4 | lead 3: 113.0-115.2 | lead 2: 114.4-115.5 | lead 1:
+        // 117.0.  The interleaving buys nothing: a piece lands ~2.6 us after its issue whatever the wave does
+        // meanwhile (every CU streams its tile at the same moment), so the transforms still start when the tile is
+        // there and run with all waves in the same VALU phase.  The default is the plain order.
+#ifndef GMC_BWD1_LEAD
+        constexpr int kLead = ACC;
+#else
+        constexpr int kLead = GMC_BWD1_LEAD < ACC ? GMC_BWD1_LEAD : ACC;   // tuning builds
+#endif
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
-            if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
-            else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
-            if (ovf && lrow + k * kRowsPerPass < n) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, a.b, r0 + l, q));
-            // the sum is needed HERE (its only user is the store after the graph loop: left alone the
-            // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
-            asm volatile("" : "+v"(acc[k]));
+        for (int k = 0; k < ACC + kLead; ++k) {
+            if (k < ACC) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
+                if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
+                else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
+                if constexpr (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, og, ostart[k], ocnt[k], q));
+                // the sum is needed HERE (its only user is the store after the graph loop: left alone the
+                // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
+                asm volatile("" : "+v"(acc[k]));
+            }
+            if (k >= kLead && nn > 0) {
+                const int j = k - kLead;
+                wait_piece(j, pieces);
+                __builtin_amdgcn_sched_barrier(0);   // the transform's LDS read must not move above the wait
+                transform(j, nn, gyn);
+            }
         }
-        STAMP(6);  // gather 2
-        dma_wait();   // my cells of graph g+1's tile have landed
-        STAMP(7);  // DMA wait
-        if (nn > 0) load_ids(r0n, nn);   // first needed after the transform and barrier A
+        STAMP(6);  // gather 2 + transform of the next graph
+        dma_wait();
+        STAMP(7);
+        if (nn > 0) load_ids(r0n, nn, cur ^ 1);   // first needed after barrier A (which also publishes the staged blocks)
         STAMP(9);
         r0 = r0n; n = nn; nn = n2;
     }
@@ -306,6 +413,10 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     gmc::v4f acc[ACC];
     uint4 pt[NT];
     float4 rc[RC];
+    // overflow lists (OVF): my rows' (start, count) and the graph's first blocks (spare LDS) are set up with the table
+    int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
+    OvfGraph og{};
+    uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
 
@@ -325,7 +436,14 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             rc[k] = reinterpret_cast<const float4 *>(a.GY2)[r0 + min(i, n - 1)];
         }
     };
-    auto commit = [&](int n) {  // table, row constants (and the zero rows the padding entries point at)
+    auto commit = [&](int r0, int n) {  // table, row constants (and the zero rows the padding entries point at)
+        if constexpr (ovf) {   // (between two barriers: nobody reads the previous graph's blocks any more)
+            const int ob = a.b.ovf_ptr[r0];
+            og = OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr, ovl, a.ovf_cap};
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, lrow + k * kRowsPerPass, ob, ostart[k], ocnt[k]);
+            ovf_stage(og, ovl, a.b.ovf_ptr[r0 + n] - ob);
+        }
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int i = threadIdx.x + k * kThreads;
@@ -344,7 +462,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     fetch(r0, n);
-    commit(n);
+    commit(r0, n);
     dma_wait();
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
@@ -366,7 +484,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
                 float4 u = gather_row<FS, W, false, NS>(bufA, nb, nullptr, l, q);
-                if (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, a.b, r0 + l, q));
+                if constexpr (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, og, ostart[k], ocnt[k], q));
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
@@ -380,13 +498,13 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
                 acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL, NS>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
-                if (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, a.b, r0 + l, q));
+                if constexpr (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, og, ostart[k], ocnt[k], q));
                 asm volatile("" : "+v"(acc[k]));
             }
         }
         dma_wait();
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
-        if (g + 1 < g1) commit(nn);
+        if (g + 1 < g1) commit(r0n, nn);
         __syncthreads();
         r0 = r0n; n = nn;
     }
@@ -434,8 +552,13 @@ int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, co
                         hipStream_t st) {
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
     const int fs = pick_fs(b->n_max, b->ell_width);
-    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk};
-    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk, 0, 0};
+    size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graphs' first overflow blocks
+        a.own_lds = (int)lds;
+        a.ovf_cap = ovf_cap_blocks(lds);
+        lds = kOvfLdsBytes;
+    }
     GmcProbeScope probe(GMC_K_BWD1_FUSED, st);
     if (b->ell_width == 8) {
         switch (fs) {

@@ -89,6 +89,17 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
         dma(s_lo);
+        // overflow lists of this graph: my rows' (start, count), the first blocks into the spare LDS
+        OvfGraph og{};
+        int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
+        if constexpr (ovf) {
+            const int ob = a.b.ovf_ptr[r0], nblk = a.b.ovf_ptr[r0 + n] - ob;
+            uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
+            og = OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr, ovl, a.ovf_cap};
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, min(lrow + k * kRowsPerPass, n - 1), ob, ostart[k], ocnt[k]);
+            ovf_stage(og, ovl, nblk);   // (published by barrier 1 of the first slice)
+        }
         float4 cn = gmc::f4_zero();   // CSL: constants of my column of the NEXT slice (threads < FS), in flight
         if (CSL && threadIdx.x < FS) cn = col_consts(s_lo * FS + (int)threadIdx.x);
         float sc[ACC];
@@ -166,7 +177,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int lc = min(l, n - 1);
                     float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
                                       : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
-                    if (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, a.b, r0 + lc, q));
+                    if constexpr (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, og, ostart[k], ocnt[k], q));
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -176,7 +187,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int l = lrow + k * kRowsPerPass;
                     if (l < n) {
                         float4 t = gather_row<FS, W, HAS_VAL, NS>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
-                        if (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, a.b, r0 + l, q));
+                        if constexpr (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, og, ostart[k], ocnt[k], q));
                         t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                         reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
                     }
@@ -228,11 +239,11 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
                     gmc::v4f h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
-                    if (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, a.b, r0 + l, q));
+                    if constexpr (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, og, ostart[k], ocnt[k], q));
                     emit(k, h);
                 } else {
                     gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
-                    if (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, a.b, r0 + l, q));
+                    if constexpr (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, og, ostart[k], ocnt[k], q));
                     emit(k, h);
                 }
             }
@@ -283,9 +294,14 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
     const int total = b->B * groups, cus = device_cus();
     const int ipw = (total + cus - 1) / cus, grid = (total + ipw - 1) / ipw;
     TileArgs a{*b, W1, (long)F, (long)fs, 1, b->ell_vals != nullptr, b->dinv, b1, 1, H, (long)fs, (long)b->R * fs,
-               F, slices, groups, W2, Zpart, ipw, 0, 0};
+               F, slices, groups, W2, Zpart, ipw, 0, 0, 0, 0};
     if (W1_slab) { a.X = W1_slab; a.x_rs = 16; a.x_slab16 = 1; a.x_rows = N; }
-    const size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
+    if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graph's first overflow blocks
+        a.own_lds = (int)lds;
+        a.ovf_cap = ovf_cap_blocks(lds);
+        lds = kOvfLdsBytes;
+    }
     GmcProbeScope probe(GMC_K_FWD1_FUSED, st);
     if (b->ell_width == 8) {
         switch (fs) {

@@ -105,24 +105,27 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     // fold the slice-group partials, ascending.  A thread owns up to kFoldElems elements (i, i + T, i + 2T);
     // every load of a round - kFoldRound partials of ALL its elements - is requested before the first add:
     // one memory round trip per round instead of one per (element, 8 partials).  A single n = 1000 graph has
-    // 32 partials (one workgroup per slice): 4 round trips where there were 12; the 160-graph batch (8
-    // partials) 1 where there were 3.  Same summation order as before: bitwise the same Z.
-    constexpr int kFoldElems = 3, kFoldRound = 8;
+    // 32 partials (one workgroup per slice): 2 round trips of 16 (round 2: 4 of 8; round 1: 12); the 160-graph
+    // batch (8 partials) 1.  Same summation order as before: bitwise the same Z.
+    constexpr int kFoldElems = 3, kFoldRound = 16;
     for (int i0 = threadIdx.x; i0 < 3 * n; i0 += kFoldElems * (int)blockDim.x) {
         float z[kFoldElems] = {};
+        int ie[kFoldElems];
+#pragma unroll
+        for (int e = 0; e < kFoldElems; ++e) ie[e] = min(i0 + e * (int)blockDim.x, 3 * n - 1);
         for (int p0 = 0; p0 < a.zparts; p0 += kFoldRound) {
             float t[kFoldElems][kFoldRound];
 #pragma unroll
-            for (int e = 0; e < kFoldElems; ++e) {
-                const int i = min(i0 + e * (int)blockDim.x, 3 * n - 1);
+            for (int u = 0; u < kFoldRound; ++u) {
+                // a partial's base is wave-uniform (scalar registers), the element index a per-lane 32-bit offset
+                const float *zu = a.Z0 + ((long)min(p0 + u, a.zparts - 1) * a.b.R + r0) * 3;
 #pragma unroll
-                for (int u = 0; u < kFoldRound; ++u)
-                    t[e][u] = p0 + u < a.zparts ? a.Z0[((long)(p0 + u) * a.b.R + r0) * 3 + i] : 0.f;
+                for (int e = 0; e < kFoldElems; ++e) t[e][u] = zu[ie[e]];
             }
 #pragma unroll
             for (int e = 0; e < kFoldElems; ++e)
 #pragma unroll
-                for (int u = 0; u < kFoldRound; ++u) z[e] += t[e][u];
+                for (int u = 0; u < kFoldRound; ++u) z[e] += p0 + u < a.zparts ? t[e][u] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < kFoldElems; ++e) {

@@ -89,6 +89,8 @@ struct TileArgs {
     int items_per_wg;    // fwd1: (graph, group) items per persistent workgroup
     int x_slab16;        // fwd1: X is the 16-column slab copy of the shared table (gmc::slab16_index) with
     int x_rows;          //       x_rows rows; 0 = row-major X (x_rs)
+    int ovf_cap;         // fwd1, OVF kernels: overflow blocks that fit into the LDS behind the kernel's regions
+    int own_lds;         //       ... which end at this byte offset
 };
 
 // block -> (graph, group): all groups of a graph on one XCD (blocks are dealt round-robin
@@ -259,30 +261,58 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
     return acc;
 }
 
-// Overflow blocks of batch row r (gmc_batch.ovf_*: the neighbours beyond the table's W slots, eight ids per block,
-// padded with the zero row): summed block by block in order.  Only rows of hub degree have any, and only the thread
-// group that owns the row runs this loop, so a hub costs its own blocks (ids and weights come from L2 / L1).
+// Overflow lists of the graph in flight (gmc_batch.ovf_*: the neighbours beyond the table's W slots of its rows,
+// eight ids per block, padded with the zero row).  Only the OVF instantiations of the fused kernels carry this.
+// The first `cap` blocks of the graph are copied into the LDS the launch has left over (a few KB: 150-200 blocks at
+// n = 1000, far more for smaller graphs), block indices are relative to the graph's first block; a row's
+// (start, count) pair is read once per graph into registers.  A row of hub degree then costs its own extra
+// ds_read_b128 per block - like a wider table row - instead of dependent global loads in every gather of every slice
+// (first version of this path, G(n, p = 0.01) batch: 1.05 ms per step).
+struct OvfGraph {
+    const uint4 *gids;     // global: ids of the graph's first block
+    const float *gvals;    // global: weights of the graph's first block, or nullptr (all ones)
+    const uint4 *lids;     // LDS: copy of the first `cap` blocks
+    int cap;
+};
+// (start, count) of row r0 + l in blocks relative to the graph's first block `ob`; rows past n: none
+__device__ __forceinline__ void ovf_row(const gmc_batch &b, int r0, int n, int l, int ob, int &start, int &cnt) {
+    const int lc = min(l, n - 1);
+    const int p0 = b.ovf_ptr[r0 + lc], p1 = b.ovf_ptr[r0 + lc + 1];
+    start = p0 - ob;
+    cnt = l < n ? p1 - p0 : 0;
+}
+// copy the first min(nblk, cap) blocks of the graph into LDS (every thread takes blocks tid, tid + T, ...)
+__device__ __forceinline__ void ovf_stage(const OvfGraph &og, uint4 *ldst, int nblk) {
+    const int m = min(nblk, og.cap);
+    for (int i = threadIdx.x; i < m; i += kThreads) ldst[i] = og.gids[i];
+}
+// Two reads in flight, not eight: the loop runs for the few rows of hub degree only, and it must not add to the
+// register pressure of the gathers it sits in (with eight rows in flight the OVF kernels spilled ~100 registers per
+// lane to scratch - vector-memory traffic inside every gather: 3x slower than the tables alone).
 template <int FS, bool HAS_VAL>
-__device__ __forceinline__ float4 gather_overflow(const float *tile, const gmc_batch &b, int r, int q) {
+__device__ __forceinline__ float4 gather_overflow(const float *tile, const OvfGraph &og, int start, int cnt, int q) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    using lds_f4 = __attribute__((address_space(3))) const v4f;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
     float4 acc = gmc::f4_zero();
-    const int b0 = b.ovf_ptr[r], b1 = b.ovf_ptr[r + 1];
-    for (int blk = b0; blk < b1; ++blk) {
-        const uint4 ids = *reinterpret_cast<const uint4 *>(b.ovf_ids + 8l * blk);
-        float4 x[8];
-        read8<8>(tile, q, FS * 4, ids, x);
-        if (HAS_VAL) {
-            const float4 w0 = *reinterpret_cast<const float4 *>(b.ovf_vals + 8l * blk);
-            const float4 w1 = *reinterpret_cast<const float4 *>(b.ovf_vals + 8l * blk + 4);
-            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) gmc::f4_fma(acc, w[u], x[u]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) gmc::f4_add(acc, x[u]);
+    for (int blk = start; blk < start + cnt; ++blk) {
+        const uint4 ids = blk < og.cap ? og.lids[blk] : og.gids[blk];
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const unsigned pk = j == 0 ? ids.x : j == 1 ? ids.y : j == 2 ? ids.z : ids.w;
+            const v4f x0 = *(lds_f4 *)(size_t)(base + (pk & 0xffffu) * (unsigned)(FS * 4));
+            const v4f x1 = *(lds_f4 *)(size_t)(base + (pk >> 16) * (unsigned)(FS * 4));
+            float w0 = 1.f, w1 = 1.f;
+            if (HAS_VAL) { w0 = og.gvals[8l * blk + 2 * j]; w1 = og.gvals[8l * blk + 2 * j + 1]; }
+            acc.x = fmaf(w0, x0.x, acc.x); acc.y = fmaf(w0, x0.y, acc.y); acc.z = fmaf(w0, x0.z, acc.z); acc.w = fmaf(w0, x0.w, acc.w);
+            acc.x = fmaf(w1, x1.x, acc.x); acc.y = fmaf(w1, x1.y, acc.y); acc.z = fmaf(w1, x1.z, acc.z); acc.w = fmaf(w1, x1.w, acc.w);
         }
     }
     return acc;
 }
+// the LDS an OVF launch asks for (all of it) and the blocks that fit behind the kernel's own regions
+constexpr size_t kOvfLdsBytes = 160 * 1024;
+inline int ovf_cap_blocks(size_t own_bytes) { return own_bytes < kOvfLdsBytes ? (int)((kOvfLdsBytes - own_bytes) / 16) : 0; }
 
 // the kernels' NS specialisation for a table of W slots of which `slots` can hold a neighbour (gmc_batch.ell_slots)
 inline int ns_class(int W, int slots, bool unit_weights) {

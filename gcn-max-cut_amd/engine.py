@@ -250,12 +250,23 @@ class FusedEngine:
         hip.check(rc, "gmc_adam_f32")
         self._slab_sig = None   # W1 moved, the slab copy did not
 
-    def adam_step_dev(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, slab: bool = False) -> None:
+    def adam_step_dev(self, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, slab: bool = False,
+                      publish: Optional[Tuple[torch.Tensor, int]] = None) -> None:
         """Same update with the step number read from (and advanced in) device memory, so the
         launch can be captured into a hipGraph and replayed (``step_dev`` must equal
         ``step_count`` on entry; both advance by one).  ``slab``: the updated conv1.weight goes to the slab
-        copy as well (which must be current: :meth:`ensure_slab`)."""
-        if slab and self.slab_enabled:
+        copy as well (which must be current: :meth:`ensure_slab`).  ``publish`` = (device floats, device-side
+        address of pinned host memory): the values are stored there by the one-wave launch that also advances the
+        step counter, in front of the Adam sweep (two launches for publish + Adam + tick instead of three)."""
+        if publish is not None:
+            src, dst = publish
+            rc = self.lib.gmc_publish_adam_devstep_model_f32(
+                hip.ptr(src), src.numel(), dst, hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m), hip.ptr(self.v),
+                self.N, self.Fp, self.ensure_slab() if (slab and self.slab_enabled) else None, lr, betas[0], betas[1], eps,
+                hip.ptr(self.step_dev), hip.stream())
+            if not (slab and self.slab_enabled):
+                self._slab_sig = None
+        elif slab and self.slab_enabled:
             rc = self.lib.gmc_adam_devstep_model_f32(hip.ptr(self.flat), hip.ptr(self.grad), hip.ptr(self.m),
                                                      hip.ptr(self.v), self.N, self.Fp, self.ensure_slab(), lr, betas[0],
                                                      betas[1], eps, hip.ptr(self.step_dev), hip.stream())
@@ -319,3 +330,36 @@ def shard_for_rank(n_items: int, rank: int, world: int) -> range:
     base, extra = divmod(n_items, world)
     start = rank * base + min(rank, extra)
     return range(start, start + base + (1 if rank < extra else 0))
+
+
+def shard_by_weight(weights: Sequence[int], rank: int, world: int) -> range:
+    """Contiguous slice of a group of graphs for one rank, balanced by WORK instead of by count (SURVEY section 8e:
+    "for mixed sizes balance by nnz"): ``weights[i]`` = directed edges of graph i.  Equal weights (the regular-graph
+    workloads) give exactly :func:`shard_for_rank`.  Otherwise the partition into ``world`` contiguous runs with the
+    smallest possible largest run: the smallest capacity for which filling rank after rank (a rank closes when the
+    next graph would exceed it) needs at most ``world`` ranks, then that filling - a pure function of the weights, so
+    every rank computes the same split without talking; trailing ranks may stay empty."""
+    w = [int(x) for x in weights]
+    n = len(w)
+    if n == 0 or world <= 1 or min(w) == max(w):
+        return shard_for_rank(n, rank, world)
+
+    def cuts(cap):
+        out, load = [0], 0
+        for i, x in enumerate(w):
+            if load and load + x > cap:
+                out.append(i)
+                load = 0
+            load += x
+        return out
+
+    lo, hi = max(w), sum(w)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(cuts(mid)) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    starts = cuts(lo)
+    starts += [n] * (world + 1 - len(starts))
+    return range(starts[rank], starts[rank + 1])

@@ -21,6 +21,7 @@ SYMBOLS = (
     "gmc_adam_f32", "gmc_workspace_bytes", "gmc_forward", "gmc_train_fwd_bwd",
     "gmc_backward_from_gp", "gmc_probe_begin", "gmc_probe_end", "gmc_set_fuse", "gmc_decode_sample_f32", "gmc_adam_devstep_f32", "gmc_ell_arrange_host", "gmc_ell_slots_for", "gmc_train_step_f32",
     "gmc_adam_devstep_model_f32", "gmc_w1_slab_floats", "gmc_w1_slab_f32", "gmc_host_device_pointer", "gmc_publish_f32",
+    "gmc_publish_adam_devstep_model_f32",
 )
 
 MAX_GRAPH_NODES = 4096
@@ -94,6 +95,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.gmc_probe_end.argtypes = [vp, vp, i32]
     lib.gmc_host_device_pointer.argtypes = [vp, C.POINTER(vp)]
     lib.gmc_publish_f32.argtypes = [vp, i32, vp, vp]
+    lib.gmc_publish_adam_devstep_model_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, C.c_double, C.c_double,
+                                                       C.c_double, C.c_double, vp, vp]
     lib.gmc_debug_set_device_cus.argtypes = [C.c_int]   # test hook (not part of gcnmaxcut.h)
     lib.gmc_debug_set_device_cus.restype = C.c_int
     for name in SYMBOLS:

@@ -239,6 +239,14 @@ int gmc_host_device_pointer(void *pinned_host, void **device_ptr);
  * thread before the optimizer kernels of that step run. */
 int gmc_publish_f32(const float *src, int32_t n, float *pinned_dst, gmc_stream_t stream);
 
+/* gmc_publish_f32 + gmc_adam_devstep_model_f32 as TWO launches instead of three: one wave stores the loss values and
+ * advances *step_counter, the Adam sweep behind it uses the counter as it then stands (no trailing one-thread launch).
+ * The tail of a data-parallel rank's step after the gradient all-reduce (TrainingNeural.py:386-388 on N GPUs). */
+int gmc_publish_adam_devstep_model_f32(const float *publish_src, int32_t publish_n, float *pinned_dst, float *param,
+                                       const float *grad, float *m, float *v, int32_t N, int32_t F, float *w1_slab,
+                                       double lr, double beta1, double beta2, double eps, int32_t *step_counter,
+                                       gmc_stream_t stream);
+
 /* bytes of scratch gmc_forward / gmc_train_fwd_bwd need for this batch and model */
 size_t gmc_workspace_bytes(const gmc_batch *batch, const gmc_model *model, int training);
 

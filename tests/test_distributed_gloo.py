@@ -70,7 +70,7 @@ class OracleEngine:
             dist.broadcast(torch.from_numpy(buf), src)
 
 
-def run_epochs(rank, world, port, graphs_per_step, queue, n_graphs=6, seed_by_rank=False):
+def run_epochs(rank, world, port, graphs_per_step, queue, n_graphs=6, seed_by_rank=False, specs=None):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
@@ -80,7 +80,7 @@ def run_epochs(rank, world, port, graphs_per_step, queue, n_graphs=6, seed_by_ra
     from tests import util
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        ds = util.product_dataset(SPECS[:n_graphs])
+        ds = util.product_dataset((specs or SPECS)[:n_graphs])
     cfg = T.TrainingConfig(n_nodes=1000, hidden_dim=HIDDEN)
     net, embed, opt = T.setup_model_and_optimizer(cfg)
     # seed_by_rank: every rank starts from its OWN random model; the trainer must make them one (rank 0's)
@@ -106,11 +106,11 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch(world, graphs_per_step, n_graphs=6, seed_by_rank=False):
+def launch(world, graphs_per_step, n_graphs=6, seed_by_rank=False, specs=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=run_epochs, args=(r, world, port, graphs_per_step, q, n_graphs, seed_by_rank)) for r in range(world)]
+    procs = [ctx.Process(target=run_epochs, args=(r, world, port, graphs_per_step, q, n_graphs, seed_by_rank, specs)) for r in range(world)]
     for p in procs:
         p.start()
     out = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
@@ -156,3 +156,17 @@ def test_replicas_start_from_rank_zeros_model(built):
     r0, r1 = launch(2, 3, seed_by_rank=True)
     assert np.array_equal(r0[2], r1[2])                        # bit-identical replicas
     assert r0[1] == r1[1] == loss1
+
+
+@pytest.mark.timeout(300)
+def test_mixed_sizes_are_split_by_edges_not_by_count(built):
+    """"for mixed sizes balance by nnz".  One graph of 420 directed edges and three of 80..96: rank 0
+    takes the big one alone, rank 1 the three small ones (a split by count would pair the big graph with a small one);
+    the step equals the single-process step over the four graphs."""
+    specs = [(60, 7, 11), (20, 4, 12), (22, 4, 13), (24, 4, 14)]
+    (_, loss1, flat1, grad1, sizes1), = launch(1, 4, n_graphs=4, specs=specs)
+    r0, r1 = launch(2, 2, n_graphs=4, specs=specs)      # 2 ranks x "2 per rank" = groups of 4, split by edges
+    assert sizes1 == [4] and r0[4] == [1] and r1[4] == [3]
+    assert r0[1] == r1[1] == loss1
+    assert np.array_equal(r0[2], r1[2]) and np.array_equal(r0[3], r1[3])
+    assert np.abs(r0[3] - grad1).max() <= 1e-5 * max(1.0, np.abs(grad1).max())

@@ -981,23 +981,43 @@ def test_bench_line_contract(pkg):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
+    # `roofline` = the dominant kernel of the TIMED step (fused layer-1 backward or forward) on the bytes it must move,
+    # with the LDS line beside the HBM one; the stand-alone SpMM the metric names is `roofline_spmm`
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0
+    assert r["kernel"] in ("fwd1_lds_kernel", "bwd1_reg_kernel") and r["in_timed_region"] is True
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["limited_by"] == "lds"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["achieved"] > 0 and len(r["also"]) == 1
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["mean_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["lds"]["peak"] == 256 * 256 * 2.4 and 0 < r["lds"]["frac"] < 1
+    rs = d["roofline_spmm"]
+    assert rs["bound"] == "hbm" and rs["peak"] == 8000.0 and abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9
+    assert "roofline_step" not in d and "survey_unfused_GBps" not in json.dumps(d)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] * 160 / (1e3 * 8) - 1) < 1e-6
     assert d["parity"]["argmax_equal"] and d["parity"]["max_abs_prob_diff"] <= 1e-4
     assert d["parity"]["max_abs_prob_diff_one_kernel_per_op"] <= 1e-4
-    # the dominant kernel of the TIMED step, priced on compulsory bytes; the reference schedule; CPU variants
-    rs = d["roofline_step"]
-    assert rs["kernel"] in ("fwd1_lds_kernel", "bwd1_reg_kernel") and rs["bound"] == "hbm" and rs["peak"] == 8000.0
-    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9 and len(rs["also"]) == 1
-    assert "roofline_fused" not in d and "survey_unfused_GBps" not in json.dumps(d)
     q = d["sequential"]
     assert q["optimizer_steps_per_epoch"] == 8 and q["value"] > 0
     assert {"A_all_threads", "A_1_thread", "B_sparse_c_1_thread"} <= set(c["variants"])
-    assert c["variants"]["A_1_thread"]["cores"] == 1 and c["cpu_model"] and c["gpu_sequential_over_cpu"] > 0
+    assert c["variants"]["A_1_thread"]["cores"] == 1 and c["cpu_model"]
+    assert c["gpu_sequential_over_cpu"] > 0 and c["gpu_sequential_over_cpu_variant_B"] > 0
+    # other degrees / graph families on the same fused kernels, each with its parity gate
+    ow = d["other_workloads"]
+    assert set(ow) == {"d8", "d12", "gnp"}
+    assert (ow["d8"]["table_slots"], ow["d8"]["live_slots"]) == (8, 8) and ow["d8"]["overflow_blocks"] == 0
+    assert (ow["d12"]["table_slots"], ow["d12"]["live_slots"]) == (16, 12) and ow["d12"]["overflow_blocks"] == 0
+    assert ow["gnp"]["table_slots"] == 16 and ow["gnp"]["overflow_blocks"] > 0 and ow["gnp"]["max_degree"] > 16
+    for w in ow.values():
+        assert w["ms_per_step"] > 0 and w["parity"]["argmax_equal"] and w["parity"]["max_abs_prob_diff"] <= 1e-4
+        assert {"fwd1_fused", "head", "bwd1_fused", "finish"} == set(w["kernels_us"])
+    # the data-parallel step on one rank over RCCL, eager against hipGraphs
+    dpp = d["dp_shard_profile"]
+    assert dpp["backend"] == "nccl" and list(dpp["by_shard"]) == ["8"]
+    rec = dpp["by_shard"]["8"]
+    assert rec["eager"]["ms_per_step"] > 0 and rec["graphs"]["ms_per_step"] > 0 and rec["allreduce_single_rank_us"] > 0
+    assert rec["faster"] in ("eager", "graphs") and rec["eager"]["host_enqueue_us"] > 0
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu(pkg):
@@ -1190,3 +1210,42 @@ def test_one_step_epochs_same_result_on_every_launch_path(pkg, monkeypatch):
     for path in ("graph", "copy"):
         assert runs[path][0] == runs["direct"][0], path
         assert np.array_equal(runs[path][1], runs["direct"][1]), path
+
+
+def test_polled_losses_nan_is_a_value_and_first_epoch_is_fast(pkg):
+    """The host watches the pinned loss slots for a BIT PATTERN ("not landed"), not for NaN: a loss that genuinely is
+    NaN (here: C = NaN) comes back at once instead of costing the 5 s polling deadline per step, and an ordinary
+    polled epoch finishes far below the deadline without ever taking the fallback."""
+    import math, time as _time
+    ds = util.product_dataset([(300, 7, 91), (200, 6, 92), (260, 8, 93)])
+    for gps in (3, 1):       # batched step (eager, zero-copy stores) and the reference schedule (hipGraph per epoch)
+        T, cfg, net, embed, opt, _ = model_and_params(pkg, 64)   # (a NaN step ruins the weights: fresh model each time)
+        tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=gps)
+        t0 = _time.perf_counter()
+        first = tr.epoch(ds)
+        assert _time.perf_counter() - t0 < 2.0 and first < 0 and tr.deadline_hits == 0 and tr._poll
+        cfg_nan = T.TrainingConfig(n_nodes=1000, hidden_dim=64, C=float("nan"))
+        tr.config = cfg_nan
+        for _ in range(3):   # (the first epoch with a new C re-captures the graph)
+            t0 = _time.perf_counter()
+            got = tr.epoch(ds)
+            assert math.isnan(got)
+        assert _time.perf_counter() - t0 < 1.0 and tr.deadline_hits == 0 and tr._poll
+        tr.config = cfg
+    # a middle item replaced in a large dict is invisible to prepare()'s probes: invalidate() re-plans
+    T, cfg, net, embed, opt, _ = model_and_params(pkg, 64)
+    big = util.product_dataset([(60, 5, 200 + i) for i in range(40)])
+    tr = T.FusedTrainer(net, opt, cfg, graphs_per_step=40)
+    tr.epoch(big)
+    plan = tr._batches
+    keys = list(big)
+    other = util.product_dataset([(64, 6, 999)])
+    big[keys[3]] = other[0]                       # not one of the probed positions (0, 5, 11, ..., 39)
+    tr.epoch(big)
+    assert tr._batches is plan
+    tr.invalidate()
+    tr.epoch(big)
+    assert tr._batches is not plan and tr._batches[0].R == 39 * 60 + 64
+    big[keys[0]] = other[0]                       # a probed position: seen without help
+    tr.epoch(big)
+    assert tr._batches[0].R == 38 * 60 + 2 * 64

@@ -226,6 +226,28 @@ def test_sharding_helpers(built):
         assert sum(parts, []) == list(range(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
     offs, total = flat_layout(1000, 500, 3)
     assert offs == [0, 500000, 500500, 502000, 502003] and total == 502003
+    # mixed sizes: contiguous runs balanced by edges, smallest possible largest run; equal weights == the count split
+    from gcn_max_cut_amd.engine import shard_by_weight
+    for n, w in [(160, 8), (20, 3), (5, 8), (0, 2), (1, 2)]:
+        assert [shard_by_weight([7000] * n, r, w) for r in range(w)] == [shard_for_rank(n, r, w) for r in range(w)]
+    split = lambda ws, w: [list(shard_by_weight(ws, r, w)) for r in range(w)]
+    assert split([420, 80, 88, 96], 2) == [[0], [1, 2, 3]]            # by count it would be [0, 1] | [2, 3]
+    assert split([10, 10, 10, 100, 10, 10], 3) == [[0, 1, 2], [3], [4, 5]]
+    assert split([5, 1], 4) == [[0], [1], [], []]
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        ws = rng.randint(1, 1000, size=rng.randint(1, 40)).tolist()
+        w = int(rng.randint(1, 9))
+        parts = split(ws, w)
+        assert sum(parts, []) == list(range(len(ws)))
+        best = max(sum(ws[i] for i in p) for p in parts)
+        # optimality against brute force over contiguous partitions (dynamic programme)
+        pre = np.r_[0, np.cumsum(ws)]
+        dp = {(0, 0): 0}
+        for k in range(1, w + 1):
+            for j in range(len(ws) + 1):
+                dp[(k, j)] = min(max(dp[(k - 1, i)], pre[j] - pre[i]) for i in range(j + 1) if (k - 1, i) in dp)
+        assert best == dp[(w, len(ws))]
 
 
 def test_bench_launcher_refuses_cleanly_without_gpus():
