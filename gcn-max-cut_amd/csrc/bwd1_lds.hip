@@ -199,31 +199,19 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         }
     };
     uint4 idr[ACC];
-    // overflow lists (OVF): my rows' (start, count) travel with the ids; the graph's first blocks sit in the spare
-    // LDS, in the half `parity` of it (the next graph's are written while this graph's are still being read)
-    int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
-    uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
-    const int ocap = a.ovf_cap / 2;
-    auto ovf_of = [&](int r0, int parity) {
-        const int ob = a.b.ovf_ptr[r0];
-        return OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr,
-                        ovl + parity * ocap, ocap};
-    };
+    // overflow lists (OVF): per-row descriptors and the graph's first blocks in the spare LDS (single copy: the OVF
+    // flavour pays a third barrier per graph to rewrite it between gather #2 of one graph and gather #1 of the next)
+    OvfLds ol{};
+    if constexpr (ovf) ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
     // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
     // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
-    auto load_ids = [&](int r0, int n, int parity) {
+    auto load_ids = [&](int r0, int n) {
         const unsigned pad = (unsigned)n * 0x10001u;
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
             const uint4 v = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(l, n - 1)) * W);
             idr[k] = l < n ? v : make_uint4(pad, pad, pad, pad);
-        }
-        if constexpr (ovf) {
-            const int ob = a.b.ovf_ptr[r0];
-#pragma unroll
-            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, lrow + k * kRowsPerPass, ob, ostart[k], ocnt[k]);
-            ovf_stage(ovf_of(r0, parity), ovl + parity * ocap, a.b.ovf_ptr[r0 + n] - ob);
         }
     };
     auto zero_pads = [&](float *buf, int n) {  // the zero rows n..n+3 the padding entries point at
@@ -273,7 +261,8 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     dma_row_consts(a.GY2, r0, n, gy0);
     fetch_tile(r0, n, KREG);
     load_hreg(r0, n);
-    load_ids(r0, n, 0);
+    load_ids(r0, n);
+    if constexpr (ovf) ovf_setup(a.b, r0, n, ol);
     zero_pads(bufA, n);
     dma_wait();
     __syncthreads();
@@ -285,8 +274,6 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         const int cur = (g - g0) & 1;
         const float *gyl = cur ? gy1 : gy0;
         float *gyn = cur ? gy0 : gy1;
-        OvfGraph og{};
-        if constexpr (ovf) og = ovf_of(r0, cur);
         const int r0n = r0 + n;                                              // == goff[g + 1]
         const int n2 = g + 2 < g1 ? a.b.goff[g + 3] - (r0n + nn) : 0;        // size of graph g+2 (0: none)
         STAMP(0);
@@ -309,9 +296,20 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
             float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
-            if constexpr (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, og, ostart[k], ocnt[k], q));   // hub rows: their own extra blocks
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+        }
+        if constexpr (ovf) {   // hub rows: their overflow blocks, added to the U row this thread has just written
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n && ovf_desc(ol, l) != 0) {
+                    const float4 t = gather_overflow<FS>(bufA, ol, l, q);
+                    float4 *cell = reinterpret_cast<float4 *>(bufB) + l * Q + q;
+                    const float4 c = *cell;
+                    *cell = make_float4(fmaf(t.x, dv[k], c.x), fmaf(t.y, dv[k], c.y), fmaf(t.z, dv[k], c.z), fmaf(t.w, dv[k], c.w));
+                }
+            }
         }
         STAMP(3);  // gather 1
         // my share of graph g+1's row constants (the KREG register loads behind it may stay in flight)
@@ -348,7 +346,6 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
                 if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
                 else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
-                if constexpr (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, og, ostart[k], ocnt[k], q));
                 // the sum is needed HERE (its only user is the store after the graph loop: left alone the
                 // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
                 asm volatile("" : "+v"(acc[k]));
@@ -360,10 +357,23 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 transform(j, nn, gyn);
             }
         }
+        if constexpr (ovf) {   // hub rows: their overflow blocks into the dW1 accumulators
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n && ovf_desc(ol, l) != 0) acc[k] += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
+            }
+        }
         STAMP(6);  // gather 2 + transform of the next graph
         dma_wait();
         STAMP(7);
-        if (nn > 0) load_ids(r0n, nn, cur ^ 1);   // first needed after barrier A (which also publishes the staged blocks)
+        if (nn > 0) load_ids(r0n, nn);   // first needed after barrier A
+        if constexpr (ovf) {
+            if (nn > 0) {   // every wave is done with this graph's descriptors / blocks before they are rewritten
+                loop_barrier();
+                ovf_setup(a.b, r0n, nn, ol);   // (published by barrier A)
+            }
+        }
         STAMP(9);
         r0 = r0n; n = nn; nn = n2;
     }
@@ -413,10 +423,9 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     gmc::v4f acc[ACC];
     uint4 pt[NT];
     float4 rc[RC];
-    // overflow lists (OVF): my rows' (start, count) and the graph's first blocks (spare LDS) are set up with the table
-    int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
-    OvfGraph og{};
-    uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
+    // overflow lists (OVF): per-row descriptors and the graph's first blocks (spare LDS) are set up with the table
+    OvfLds ol{};
+    if constexpr (ovf) ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
 
@@ -437,13 +446,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
         }
     };
     auto commit = [&](int r0, int n) {  // table, row constants (and the zero rows the padding entries point at)
-        if constexpr (ovf) {   // (between two barriers: nobody reads the previous graph's blocks any more)
-            const int ob = a.b.ovf_ptr[r0];
-            og = OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr, ovl, a.ovf_cap};
-#pragma unroll
-            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, lrow + k * kRowsPerPass, ob, ostart[k], ocnt[k]);
-            ovf_stage(og, ovl, a.b.ovf_ptr[r0 + n] - ob);
-        }
+        if constexpr (ovf) ovf_setup(a.b, r0, n, ol);   // (between two barriers: nobody reads the previous graph's any more)
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int i = threadIdx.x + k * kThreads;
@@ -484,9 +487,20 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
                 float4 u = gather_row<FS, W, false, NS>(bufA, nb, nullptr, l, q);
-                if constexpr (ovf) gmc::f4_add(u, gather_overflow<FS, false>(bufA, og, ostart[k], ocnt[k], q));
                 u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
+            }
+        }
+        if constexpr (ovf) {   // hub rows: their overflow blocks, added to the U row this thread has just written
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n && ovf_desc(ol, l) != 0) {
+                    const float4 t = gather_overflow<FS>(bufA, ol, l, q);
+                    float4 *cell = reinterpret_cast<float4 *>(bufB) + l * Q + q;
+                    const float4 c = *cell;
+                    *cell = make_float4(fmaf(t.x, dv[k], c.x), fmaf(t.y, dv[k], c.y), fmaf(t.z, dv[k], c.z), fmaf(t.w, dv[k], c.w));
+                }
             }
         }
         __syncthreads();
@@ -498,8 +512,14 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             const int l = lrow + k * kRowsPerPass;
             if (l < n) {
                 acc[k] += gmc::f4v(gather_row<FS, W, HAS_VAL, NS>(bufB, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q));
-                if constexpr (ovf) acc[k] += gmc::f4v(gather_overflow<FS, HAS_VAL>(bufB, og, ostart[k], ocnt[k], q));
                 asm volatile("" : "+v"(acc[k]));
+            }
+        }
+        if constexpr (ovf) {   // hub rows: their overflow blocks into the dW1 accumulators
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = lrow + k * kRowsPerPass;
+                if (l < n && ovf_desc(ol, l) != 0) acc[k] += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
             }
         }
         dma_wait();
@@ -530,13 +550,13 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     if constexpr (W == 8) {
 #define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_reg_kernel<FS, 4, HV, NSK, OV>, grid, lds, st, a) \
                                         : launch(bwd1_reg_kernel<FS, 8, HV, NSK, OV>, grid, lds, st, a))
-        if (ov) return hv ? GMC_BWD1(true, 8, true) : GMC_BWD1(false, 8, true);
+        if (ov) return hv ? GMC_ERR_UNSUPPORTED : GMC_BWD1(false, 8, true);   // (weights + overflow: row kernels, see gmc_lds_fits)
         return hv ? GMC_BWD1(true, 8, false) : ns == 7 ? GMC_BWD1(false, 7, false) : GMC_BWD1(false, 8, false);
 #undef GMC_BWD1
     } else {
 #define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_lds_kernel<FS, W, 4, HV, NSK, OV>, grid, lds, st, a) \
                                         : launch(bwd1_lds_kernel<FS, W, 8, HV, NSK, OV>, grid, lds, st, a))
-        if (ov) return hv ? GMC_BWD1(true, 16, true) : GMC_BWD1(false, 16, true);
+        if (ov) return hv ? GMC_ERR_UNSUPPORTED : GMC_BWD1(false, 16, true);
         return hv ? GMC_BWD1(true, 16, false) : ns == 10 ? GMC_BWD1(false, 10, false) : ns == 12 ? GMC_BWD1(false, 12, false)
                   : ns == 14 ? GMC_BWD1(false, 14, false) : GMC_BWD1(false, 16, false);
 #undef GMC_BWD1
@@ -555,8 +575,10 @@ int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, co
     Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk, 0, 0};
     size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graphs' first overflow blocks
-        a.own_lds = (int)lds;
-        a.ovf_cap = ovf_cap_blocks(lds);
+        const size_t own = ovf_own_bytes(1, b->n_max, b->ell_width, fs);
+        if (own + ovf_desc_bytes(b->n_max) > kOvfLdsBytes) return GMC_ERR_UNSUPPORTED;   // (gmc_lds_fits says so beforehand)
+        a.own_lds = (int)own;
+        a.ovf_cap = ovf_cap_blocks(own, b->n_max);
         lds = kOvfLdsBytes;
     }
     GmcProbeScope probe(GMC_K_BWD1_FUSED, st);

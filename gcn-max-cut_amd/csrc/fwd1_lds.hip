@@ -84,21 +84,22 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
             const int col = s * FS + 4 * q;
             const int cs = min(col, ((a.F + 15) & ~15) - 4);
             const long off = a.x_slab16 ? gmc::slab16_index(0, cs, a.x_rows) : (long)min(col, a.F - 4);
-            dma_tile<FS, ACC>(a.X + off, a.x_rs, n, true, lrow, bufA);
+            int lr = lrow;
+            // OVF kernels: recompute the pieces' addresses here.  Hoisted out of the slice loop they are spilled, and the
+            // reload in front of each piece comes with s_waitcnt vmcnt(0) - a wait for every H store of the previous
+            // gather before the next tile's DMA may even start (that, not the hub rows, cost the OVF forward 2x)
+            if constexpr (ovf) asm volatile("" : "+v"(lr));
+            dma_tile<FS, ACC>(a.X + off, a.x_rs, n, true, lr, bufA);
         };
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
         dma(s_lo);
-        // overflow lists of this graph: my rows' (start, count), the first blocks into the spare LDS
-        OvfGraph og{};
-        int ostart[ovf ? ACC : 1], ocnt[ovf ? ACC : 1];
+        // overflow lists of this graph: per-row descriptors and the first blocks into the spare LDS (published by
+        // barrier 1 of the first slice; the previous graph's readers are behind the barrier above)
+        OvfLds ol{};
         if constexpr (ovf) {
-            const int ob = a.b.ovf_ptr[r0], nblk = a.b.ovf_ptr[r0 + n] - ob;
-            uint4 *ovl = reinterpret_cast<uint4 *>(reinterpret_cast<char *>(lds) + a.own_lds);
-            og = OvfGraph{reinterpret_cast<const uint4 *>(a.b.ovf_ids) + ob, a.b.ovf_vals ? a.b.ovf_vals + 8l * ob : nullptr, ovl, a.ovf_cap};
-#pragma unroll
-            for (int k = 0; k < ACC; ++k) ovf_row(a.b, r0, n, min(lrow + k * kRowsPerPass, n - 1), ob, ostart[k], ocnt[k]);
-            ovf_stage(og, ovl, nblk);   // (published by barrier 1 of the first slice)
+            ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
+            ovf_setup(a.b, r0, n, ol);
         }
         float4 cn = gmc::f4_zero();   // CSL: constants of my column of the NEXT slice (threads < FS), in flight
         if (CSL && threadIdx.x < FS) cn = col_consts(s_lo * FS + (int)threadIdx.x);
@@ -177,7 +178,6 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int lc = min(l, n - 1);
                     float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
                                       : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
-                    if constexpr (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, og, ostart[k], ocnt[k], q));
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -187,9 +187,21 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     const int l = lrow + k * kRowsPerPass;
                     if (l < n) {
                         float4 t = gather_row<FS, W, HAS_VAL, NS>(bufA, nb, HAS_VAL ? wbase + (long)l * W : nullptr, l, q);
-                        if constexpr (ovf) gmc::f4_add(t, gather_overflow<FS, HAS_VAL>(bufA, og, ostart[k], ocnt[k], q));
                         t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                         reinterpret_cast<float4 *>(bufB)[l * Q + q] = t;
+                    }
+                }
+            }
+            if constexpr (ovf) {   // hub rows: add their overflow blocks to the T0 row this thread has just written
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const int lc = min(lrow + k * kRowsPerPass, n - 1);
+                    // (rows past n: the thread that OWNS row n-1 adds - a read-modify-write is not idempotent)
+                    if (lrow + k * kRowsPerPass < n && ovf_desc(ol, lc) != 0) {
+                        float4 t = gather_overflow<FS>(bufA, ol, lc, q);
+                        float4 *cell = reinterpret_cast<float4 *>(bufB) + lc * Q + q;
+                        const float4 c = *cell;
+                        *cell = make_float4(fmaf(t.x, sc[k], c.x), fmaf(t.y, sc[k], c.y), fmaf(t.z, sc[k], c.z), fmaf(t.w, sc[k], c.w));
                     }
                 }
             }
@@ -235,16 +247,29 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);
+                // hub rows (OVF kernels, a 16-bit LDS word tells) are emitted by the fix-up loop below, with their
+                // overflow blocks: H is relu of the WHOLE sum.  Every thread still stores exactly ACC rows per slice.
+                bool later = false;
+                if constexpr (ovf) later = ovf_desc(ol, l) != 0;
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                    gmc::v4f h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
-                    if constexpr (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, og, ostart[k], ocnt[k], q));
-                    emit(k, h);
+                    const gmc::v4f h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
+                    if (!later) emit(k, h);
                 } else {
-                    gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
-                    if constexpr (ovf) h += gmc::f4v(gather_overflow<FS, false>(bufB, og, ostart[k], ocnt[k], q));
-                    emit(k, h);
+                    const gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
+                    if (!later) emit(k, h);
+                }
+            }
+            if constexpr (ovf) {
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const int l = min(lrow + k * kRowsPerPass, n - 1);
+                    if (ovf_desc(ol, l) != 0) {
+                        gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
+                        h += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
+                        emit(k, h);
+                    }
                 }
             }
             STAMP(6);  // gather 2
@@ -266,7 +291,10 @@ int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
     const int ns = ns_class(W, a.b.ell_slots, !a.use_vals);
 #define GMC_FWD1(AC, HV, NSK, OV) launch(fwd1_lds_kernel<FS, W, AC, HV, NSK, OV>, grid, lds, st, a)
 #define GMC_FWD1_ACC(HV, NSK, OV) (acc <= 4 ? GMC_FWD1(4, HV, NSK, OV) : GMC_FWD1(8, HV, NSK, OV))
-    if (a.b.ovf_ptr) return a.use_vals ? GMC_FWD1_ACC(true, W, true) : GMC_FWD1_ACC(false, W, true);   // hub rows: every slot live
+    if (a.b.ovf_ptr) {   // hub rows: every slot live (weights + overflow: row kernels, see gmc_lds_fits)
+        if (a.use_vals) return GMC_ERR_UNSUPPORTED;
+        return GMC_FWD1_ACC(false, W, true);
+    }
     if (a.use_vals) return GMC_FWD1_ACC(true, W, false);
     if constexpr (W == 8) return ns == 7 ? GMC_FWD1_ACC(false, 7, false) : GMC_FWD1_ACC(false, 8, false);
     else return ns == 10 ? GMC_FWD1_ACC(false, 10, false) : ns == 12 ? GMC_FWD1_ACC(false, 12, false)
@@ -298,8 +326,10 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
     if (W1_slab) { a.X = W1_slab; a.x_rs = 16; a.x_slab16 = 1; a.x_rows = N; }
     size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graph's first overflow blocks
-        a.own_lds = (int)lds;
-        a.ovf_cap = ovf_cap_blocks(lds);
+        const size_t own = ovf_own_bytes(0, b->n_max, b->ell_width, fs);
+        if (own + ovf_desc_bytes(b->n_max) > kOvfLdsBytes) return GMC_ERR_UNSUPPORTED;   // (gmc_lds_fits says so beforehand)
+        a.own_lds = (int)own;
+        a.ovf_cap = ovf_cap_blocks(own, b->n_max);
         lds = kOvfLdsBytes;
     }
     GmcProbeScope probe(GMC_K_FWD1_FUSED, st);

@@ -67,6 +67,15 @@ __device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l
 #pragma unroll
             for (int u = 0; u < 8; ++u) f((int)id[u], b.ell_vals ? b.ell_vals[(long)(r0 + l) * W + blk * 8 + u] : 1.0f);
         }
+        if (b.ovf_ptr) {  // rows of hub degree: their overflow blocks (padding ids hit the zeroed slots as well)
+            for (int blk = b.ovf_ptr[r0 + l]; blk < b.ovf_ptr[r0 + l + 1]; ++blk) {
+                const uint4 ids = reinterpret_cast<const uint4 *>(b.ovf_ids)[blk];
+                const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
+                                        ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) f((int)id[u], b.ovf_vals ? b.ovf_vals[8l * blk + u] : 1.0f);
+            }
+        }
     } else {
         for (int e = b.rowptr[r0 + l]; e < b.rowptr[r0 + l + 1]; ++e) f(b.lcol[e], b.vals ? b.vals[e] : 1.0f);
     }
@@ -282,8 +291,7 @@ int gmc_head_launch(const gmc_batch *batch, const float *Z0, int32_t z_parts, co
     if (batch->B == 0) return GMC_OK;
     HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, tick};
     const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
-    // (rows with overflow lists: the CSR walk covers every neighbour)
-    const bool ell = batch->ell != nullptr && batch->ell_width > 0 && !batch->ovf_ptr;
+    const bool ell = batch->ell != nullptr && batch->ell_width > 0;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(ell ? reinterpret_cast<const void *>(head_kernel<true>)
                                                : reinterpret_cast<const void *>(head_kernel<false>),

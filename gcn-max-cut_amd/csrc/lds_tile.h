@@ -263,56 +263,92 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
 
 // Overflow lists of the graph in flight (gmc_batch.ovf_*: the neighbours beyond the table's W slots of its rows,
 // eight ids per block, padded with the zero row).  Only the OVF instantiations of the fused kernels carry this.
-// The first `cap` blocks of the graph are copied into the LDS the launch has left over (a few KB: 150-200 blocks at
-// n = 1000, far more for smaller graphs), block indices are relative to the graph's first block; a row's
-// (start, count) pair is read once per graph into registers.  A row of hub degree then costs its own extra
-// ds_read_b128 per block - like a wider table row - instead of dependent global loads in every gather of every slice
-// (first version of this path, G(n, p = 0.01) batch: 1.05 ms per step).
-struct OvfGraph {
-    const uint4 *gids;     // global: ids of the graph's first block
-    const float *gvals;    // global: weights of the graph's first block, or nullptr (all ones)
-    const uint4 *lids;     // LDS: copy of the first `cap` blocks
-    int cap;
+// Everything a gather needs lives in the LDS the launch has left over behind the kernel's own regions (a few KB):
+//   desc[n_max]  one 16-bit word per row: (blocks << 12) | first block relative to the graph's first; 0 = none (97-100 %
+//                of the rows) - ONE ds_read_u16 per row and gather tells, no register is held across the slice loop;
+//   blocks[cap]  the graph's first `cap` blocks of eight ids (the rest, if any, is read from L2).
+// Nothing of it may sit in registers or be reached through generic pointers: the OVF kernels' first versions kept a
+// row's (start, count) in registers / called a helper - 300-500 B of scratch per lane, and every spill reload (and
+// every flat load) inside a gather is a vector-memory operation the compiler fences with vmcnt(0), i.e. a wait for the
+// tile DMA in flight behind the gather: ONE hub row in ONE graph of 160 made the step 2.3x slower (219 / 267 us
+// against 88 / 112), a G(n, p = 0.01) batch 4.3x (scratch/ovf_probe.py, profiles/r03_ablation.json).
+struct OvfLds {
+    unsigned desc;    // LDS byte address of desc[]
+    unsigned blocks;  // LDS byte address of blocks[]
+    int cap;          // blocks that fit
 };
-// (start, count) of row r0 + l in blocks relative to the graph's first block `ob`; rows past n: none
-__device__ __forceinline__ void ovf_row(const gmc_batch &b, int r0, int n, int l, int ob, int &start, int &cnt) {
-    const int lc = min(l, n - 1);
-    const int p0 = b.ovf_ptr[r0 + lc], p1 = b.ovf_ptr[r0 + lc + 1];
-    start = p0 - ob;
-    cnt = l < n ? p1 - p0 : 0;
+constexpr int kOvfMaxBlocksPerRow = 15, kOvfMaxBlocksPerGraph = 4095;   // what a 16-bit descriptor can say
+// the LDS an OVF launch asks for (all of it) and how the spare behind the kernel's `own_bytes` is split
+constexpr size_t kOvfLdsBytes = 160 * 1024;
+__host__ __device__ inline size_t ovf_desc_bytes(int n_max) { return ((size_t)n_max * 2 + 15) & ~(size_t)15; }
+inline int ovf_cap_blocks(size_t own_bytes, int n_max) {
+    const size_t used = own_bytes + ovf_desc_bytes(n_max);
+    return used < kOvfLdsBytes ? (int)((kOvfLdsBytes - used) / 16) : 0;
 }
-// copy the first min(nblk, cap) blocks of the graph into LDS (every thread takes blocks tid, tid + T, ...)
-__device__ __forceinline__ void ovf_stage(const OvfGraph &og, uint4 *ldst, int nblk) {
-    const int m = min(nblk, og.cap);
-    for (int i = threadIdx.x; i < m; i += kThreads) ldst[i] = og.gids[i];
+// LDS the fused forward (kernel 0) / backward (kernel 1) themselves use for graphs of n_max nodes: what the OVF
+// flavours have to stay behind.  16-slot tables: only the constants these two kernels really keep (the forward two
+// slices' worth, the backward none) - n = 1000 then leaves 2.8 / 3.3 KB: the 2 KB of descriptors and 51 / 83 blocks.
+inline size_t ovf_own_bytes(int kernel, int n_max, int W, int FS) {
+    if (W != 16) return lds_bytes(n_max, W, FS);
+    return 2 * tile_floats(n_max, FS) * 4 + (size_t)n_max * 32 + (kernel == 0 ? (size_t)2 * FS * 16 : 0);
 }
-// Two reads in flight, not eight: the loop runs for the few rows of hub degree only, and it must not add to the
-// register pressure of the gathers it sits in (with eight rows in flight the OVF kernels spilled ~100 registers per
-// lane to scratch - vector-memory traffic inside every gather: 3x slower than the tables alone).
-template <int FS, bool HAS_VAL>
-__device__ __forceinline__ float4 gather_overflow(const float *tile, const OvfGraph &og, int start, int cnt, int q) {
+// do the descriptors and EVERY overflow block of the batch's fullest graph fit behind both kernels' own LDS?  (The
+// gathers must not contain a single global load, not even on a rare path: the compiler closes a branch that holds
+// one with s_waitcnt vmcnt(0) at the join, which every row then executes - a wait for the tile DMA in flight.)
+inline bool ovf_fits(int n_max, int W, int FS, int max_blocks) {
+    for (int kernel = 0; kernel < 2; ++kernel) {
+        const size_t own = ovf_own_bytes(kernel, n_max, W, FS);
+        if (own + ovf_desc_bytes(n_max) > kOvfLdsBytes || ovf_cap_blocks(own, n_max) < max_blocks) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ OvfLds ovf_lds(const float *lds_base, int own_bytes, int n_max, int cap) {
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)lds_base + (unsigned)own_bytes;
+    return OvfLds{base, base + (unsigned)ovf_desc_bytes(n_max), cap};
+}
+// set up desc[] and blocks[] for the graph at rows [r0, r0 + n); callers separate this from the gathers that read the
+// previous graph's with a barrier on either side
+__device__ __forceinline__ void ovf_setup(const gmc_batch &b, int r0, int n, const OvfLds &o) {
+    using lds_u16 = __attribute__((address_space(3))) unsigned short;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    using lds_u4 = __attribute__((address_space(3))) u4;
+    const int ob = b.ovf_ptr[r0], nblk = b.ovf_ptr[r0 + n] - ob;
+    for (int i = threadIdx.x; i < n; i += kThreads) {
+        const int p0 = b.ovf_ptr[r0 + i], p1 = b.ovf_ptr[r0 + i + 1];
+        *(lds_u16 *)(size_t)(o.desc + 2u * (unsigned)i) = (unsigned short)(p1 > p0 ? ((p1 - p0) << 12) | (p0 - ob) : 0);
+    }
+    const uint4 *src = reinterpret_cast<const uint4 *>(b.ovf_ids) + ob;
+    for (int i = threadIdx.x; i < min(nblk, o.cap); i += kThreads) {
+        const uint4 v = src[i];
+        *(lds_u4 *)(size_t)(o.blocks + 16u * (unsigned)i) = (u4){v.x, v.y, v.z, v.w};
+    }
+}
+// a row's descriptor word (0: no overflow blocks)
+__device__ __forceinline__ unsigned ovf_desc(const OvfLds &o, int l) {
+    using lds_u16 = __attribute__((address_space(3))) const unsigned short;
+    return *(lds_u16 *)(size_t)(o.desc + 2u * (unsigned)l);
+}
+// overflow part of row l's sum (0 for the rows that have none: one 16-bit LDS read); one tile read at a time, LDS
+// only.  Callers keep this OUT of their gather loops (a fix-up loop over the thread's rows behind the main loop).
+template <int FS>
+__device__ __forceinline__ float4 gather_overflow(const float *tile, const OvfLds &o, int l, int q) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     using lds_f4 = __attribute__((address_space(3))) const v4f;
-    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
+    using lds_u32 = __attribute__((address_space(3))) const unsigned;
     float4 acc = gmc::f4_zero();
-    for (int blk = start; blk < start + cnt; ++blk) {
-        const uint4 ids = blk < og.cap ? og.lids[blk] : og.gids[blk];
+    const unsigned d = ovf_desc(o, l);
+    if (d == 0) return acc;
+    const unsigned tile_q = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            const unsigned pk = j == 0 ? ids.x : j == 1 ? ids.y : j == 2 ? ids.z : ids.w;
-            const v4f x0 = *(lds_f4 *)(size_t)(base + (pk & 0xffffu) * (unsigned)(FS * 4));
-            const v4f x1 = *(lds_f4 *)(size_t)(base + (pk >> 16) * (unsigned)(FS * 4));
-            float w0 = 1.f, w1 = 1.f;
-            if (HAS_VAL) { w0 = og.gvals[8l * blk + 2 * j]; w1 = og.gvals[8l * blk + 2 * j + 1]; }
-            acc.x = fmaf(w0, x0.x, acc.x); acc.y = fmaf(w0, x0.y, acc.y); acc.z = fmaf(w0, x0.z, acc.z); acc.w = fmaf(w0, x0.w, acc.w);
-            acc.x = fmaf(w1, x1.x, acc.x); acc.y = fmaf(w1, x1.y, acc.y); acc.z = fmaf(w1, x1.z, acc.z); acc.w = fmaf(w1, x1.w, acc.w);
-        }
+    for (unsigned i = 4u * (d & 0xfffu), e = i + 4u * (d >> 12); i < e; ++i) {   // i = 4 * block + pair of ids
+        const unsigned pk = *(lds_u32 *)(size_t)(o.blocks + 4u * i);
+        const v4f x0 = *(lds_f4 *)(size_t)(tile_q + (pk & 0xffffu) * (unsigned)(FS * 4));
+        acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
+        const v4f x1 = *(lds_f4 *)(size_t)(tile_q + (pk >> 16) * (unsigned)(FS * 4));
+        acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
     }
     return acc;
 }
-// the LDS an OVF launch asks for (all of it) and the blocks that fit behind the kernel's own regions
-constexpr size_t kOvfLdsBytes = 160 * 1024;
-inline int ovf_cap_blocks(size_t own_bytes) { return own_bytes < kOvfLdsBytes ? (int)((kOvfLdsBytes - own_bytes) / 16) : 0; }
 
 // the kernels' NS specialisation for a table of W slots of which `slots` can hold a neighbour (gmc_batch.ell_slots)
 inline int ns_class(int W, int slots, bool unit_weights) {

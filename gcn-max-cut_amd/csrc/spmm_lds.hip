@@ -350,7 +350,11 @@ bool gmc_lds_fits(const gmc_batch *b) {
     const int fs = pick_fs(b->n_max, b->ell_width);
     if (!fs) return false;
     const int rows_per_pass = kThreads / (fs / 4);
-    return (b->n_max + rows_per_pass - 1) / rows_per_pass <= 8;
+    if ((b->n_max + rows_per_pass - 1) / rows_per_pass > 8) return false;
+    // overflow lists: their per-row descriptors have to fit behind the fused kernels' own LDS (n <= ~1004 with 8-slot
+    // tables at 16-column tiles; larger graphs with hub rows take the row kernels)
+    // (and no edge weights: the overflow blocks' weights would have to be read from global memory inside a gather)
+    return !b->ovf_ptr || (!b->ell_vals && ovf_fits(b->n_max, b->ell_width, fs, b->ovf_max_blocks));
 }
 
 bool gmc_bwd1_fits(const gmc_batch *b) { return gmc_lds_fits(b); }

@@ -182,6 +182,7 @@ class BatchArrays:
         # (blocks of eight ids per row): a hub node costs its own extra blocks, the batch stays on the LDS path.
         ell = ell_vals = None
         ovf_ptr = ovf_ids = ovf_vals = None
+        ovf_max_blocks = 0
         ell_slots = 0
         max_deg = int(degi.max()) if degi.size else 0
         R = int(goff[-1])
@@ -201,6 +202,12 @@ class BatchArrays:
                 blocks = (np.maximum(deg64 - W, 0) + 7) // 8
                 ovf_ptr = np.zeros(R + 1, np.int64)
                 np.cumsum(blocks, out=ovf_ptr[1:])
+                # what the kernels' 16-bit row descriptors can say: <= 15 blocks per row (degree <= W + 120), <= 4095
+                # blocks per graph; beyond that the batch takes the row kernels
+                ovf_max_blocks = int(np.diff(ovf_ptr[goff]).max())
+                if int(blocks.max()) > 15 or ovf_max_blocks > 4095:
+                    W = 0
+            if W and max_deg > W:
                 nblk = int(ovf_ptr[-1])
                 ovf_ids = np.repeat(n_of_row.astype(np.uint16), blocks * 8)       # padding: the zero row of the graph
                 where = ovf_ptr[:-1][rows[~inside]] * 8 + (slot[~inside] - W)
@@ -209,6 +216,10 @@ class BatchArrays:
                     ovf_vals = np.zeros(nblk * 8, np.float32)
                     ovf_vals[where] = vals[~inside]
                 ovf_ptr = ovf_ptr.astype(np.int32)
+            if not W:
+                ell = ell_vals = ovf_ptr = None
+                ovf_max_blocks = 0
+        if W and int(ns.max()) < 65535:
             # LDS-bank-aware slot order (host routine of the library; plain CSR order otherwise)
             try:
                 lib = hip.load()
@@ -230,6 +241,7 @@ class BatchArrays:
         self.ell, self.ell_vals, self.ell_width = ell, ell_vals, (W if ell is not None else 0)
         self.ell_slots = ell_slots if ell is not None else 0   # (without the library: CSR slot order, every slot live)
         self.ovf_ptr, self.ovf_ids, self.ovf_vals = ovf_ptr, ovf_ids, ovf_vals
+        self.ovf_max_blocks = ovf_max_blocks if ovf_ptr is not None else 0
         self.max_degree = max_deg
 
     @staticmethod
@@ -273,7 +285,8 @@ class GraphBatch:
             goff=hip.ptr(self.goff), rowptr=hip.ptr(self.rowptr), gcol=hip.ptr(self.gcol),
             lcol=hip.ptr(self.lcol), vals=hip.ptr(self.vals), dinv=hip.ptr(self.dinv),
             ell=hip.ptr(self.ell), ell_vals=hip.ptr(self.ell_vals), ell_width=h.ell_width, ell_slots=h.ell_slots,
-            ovf_ptr=hip.ptr(self.ovf_ptr), ovf_ids=hip.ptr(self.ovf_ids), ovf_vals=hip.ptr(self.ovf_vals))
+            ovf_ptr=hip.ptr(self.ovf_ptr), ovf_ids=hip.ptr(self.ovf_ids), ovf_vals=hip.ptr(self.ovf_vals),
+            ovf_max_blocks=h.ovf_max_blocks)
 
     def ref(self):
         return C.byref(self.c)

@@ -40,7 +40,7 @@ class GmcBatch(C.Structure):
         ("goff", C.c_void_p), ("rowptr", C.c_void_p), ("gcol", C.c_void_p), ("lcol", C.c_void_p),
         ("vals", C.c_void_p), ("dinv", C.c_void_p),
         ("ell", C.c_void_p), ("ell_vals", C.c_void_p), ("ell_width", C.c_int32), ("ell_slots", C.c_int32),
-        ("ovf_ptr", C.c_void_p), ("ovf_ids", C.c_void_p), ("ovf_vals", C.c_void_p),
+        ("ovf_ptr", C.c_void_p), ("ovf_ids", C.c_void_p), ("ovf_vals", C.c_void_p), ("ovf_max_blocks", C.c_int32),
     ]
 
     def __init__(self, **kw):

@@ -89,6 +89,11 @@ typedef struct gmc_batch {
     const int32_t *ovf_ptr;   /* [R+1] in blocks, or NULL */
     const uint16_t *ovf_ids;  /* [8 * ovf_ptr[R]] */
     const float *ovf_vals;    /* [8 * ovf_ptr[R]] or NULL when all ones */
+    /* largest number of overflow blocks one graph of the batch has (host-known: the pointers above are device memory).
+     * The fused LDS kernels keep a graph's blocks and one 16-bit descriptor per row in the few KB of LDS their tiles
+     * leave over - at most 15 blocks per row, and as many per graph as fit (51 at n = 1000 with a 16-slot table, more
+     * for smaller graphs); a batch beyond that, or one with edge weights AND overflow lists, runs on the row kernels. */
+    int32_t ovf_max_blocks;
 } gmc_batch;
 
 /* GCNSoftmax parameters in DGL GraphConv layout (TrainingNeural.py:72-77):

@@ -89,7 +89,7 @@ def test_structs_carry_the_abi_word_and_it_is_checked(built):
     assert hip.GmcBatch._fields_[0][0] == "abi" and hip.GmcModel._fields_[0][0] == "abi"
     assert hip.GmcBatch().abi == hip.ABI_VERSION and hip.GmcModel().abi == hip.ABI_VERSION
     names = [f[0] for f in hip.GmcBatch._fields_]
-    assert names[-3:] == ["ovf_ptr", "ovf_ids", "ovf_vals"] and "ell_slots" in names
+    assert names[-4:] == ["ovf_ptr", "ovf_ids", "ovf_vals", "ovf_max_blocks"] and "ell_slots" in names
     old_b, old_m = hip.GmcBatch(abi=100), hip.GmcModel(abi=100)
     some = C.c_void_p(4096)
     assert lib.gmc_workspace_bytes(C.byref(hip.GmcBatch()), C.byref(hip.GmcModel()), 1) >= 0

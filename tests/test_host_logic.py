@@ -131,7 +131,7 @@ def test_batch_layout_table_width_and_overflow_lists(built):
     b = built.BatchArrays(hs)
     assert (b.ell_width, b.ell_slots, b.max_degree) == (8, 8, 40)
     assert b.ovf_ptr.dtype == np.int32 and b.ovf_ptr.shape == (1601,) and int(b.ovf_ptr[-1]) == 4
-    assert b.ovf_ids.shape == (32,) and b.ovf_vals is None
+    assert b.ovf_ids.shape == (32,) and b.ovf_vals is None and b.ovf_max_blocks == 4
     for g, h in enumerate(hs):
         r0 = int(b.goff[g])
         for l in range(h.n):
