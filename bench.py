@@ -181,10 +181,12 @@ def self_launch(args) -> int:
         print(f"bench.py: --gpus {args.gpus} but {have} HIP device(s) visible; refusing to launch "
               f"(set GCN_MAXCUT_BENCH_REHEARSE=1 to rehearse N ranks on one device over gloo)", file=sys.stderr)
         return 2
-    port = free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torch.distributed.run brings up its own rendezvous store on a port IT finds free (nothing is probed
+    # here and handed over later, which another process could grab in between); --local-addr: the container's hostname
+    # may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 

@@ -43,7 +43,39 @@ with open(f"profiles/{rnd}_bench_kernel_stats_by_grid.csv", "w") as out:
     w.writerow(["kernel", "workgroups", "calls", "avg_us", "min_us", "max_us", "total_ms"])
     for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         w.writerow([k, g, len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}", f"{sum(v)/1e3:.2f}"])
+# the headline's timed region is the LAST thing the process does: its K steps are the last K launches of each of the
+# four step kernels (the 256-workgroup backward is also launched by the data-parallel profile's 80-graph shards, so
+# the by-grid table mixes two batch sizes in that row)
 line = [l for l in open(f"gpurun_out/prof_{tag}/bench_line.json") if l.startswith("{")][-1]
+K = json.loads(line)["steps"]
+rows_t = [r for r in csv.DictReader(open(find(f"prof_{tag}", "_kernel_trace.csv")))]
+rows_t.sort(key=lambda r: int(r["Start_Timestamp"]))
+with open(f"profiles/{rnd}_bench_kernel_stats_timed_region.csv", "w") as out:
+    w = csv.writer(out)
+    w.writerow(["kernel", "workgroups", "calls (= --steps: the last K launches of the process)", "avg_us", "min_us", "max_us"])
+    # the headline's launch shapes: forward / backward on 256 workgroups (NS = 7 flavours), head on one workgroup per
+    # graph, fold + Adam on 489 - the parity gate's one-graph forwards behind the timed region have other grids
+    bl = json.loads(line)
+    B = bl["config"]["graphs_per_gpu"]
+    shapes = (("fwd1_lds_kernel<16, 8, 4, false, 7, false>", 256), ("head_kernel", B),
+              ("bwd1_reg_kernel<16, 4, false, 7, false>", 256), ("finish_kernel", 489))
+    step_rows = []
+    for key, wgs in shapes:
+        mine = [r for r in rows_t if key in r["Kernel_Name"] and workgroups(r) == wgs][-K:]
+        step_rows += mine
+        v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in mine]
+        w.writerow([short(mine[-1]["Kernel_Name"]), wgs, len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
+    step_rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    span = (int(step_rows[-1]["End_Timestamp"]) - int(step_rows[0]["Start_Timestamp"])) / 1e3
+    # the launches bench.py's HIP events bracket (`kernels_ms`, `roofline`): the probe region = the FIRST launches of
+    # these shapes in the process, 150 untimed steps then K probed ones
+    for key, wgs in shapes:
+        mine = [r for r in rows_t if key in r["Kernel_Name"] and workgroups(r) == wgs][150:150 + K]
+        v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in mine]
+        tag_ = {"fwd1": "fwd1_fused", "head": "head", "bwd1": "bwd1_fused", "fini": "finish"}[key[:4]]
+        w.writerow([short(mine[-1]["Kernel_Name"]) + " - the K launches of the probe region (HIP events of the same run: "
+                    f"{1e3 * bl['kernels_ms'][tag_]:.2f} us)", wgs, len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
+    w.writerow(["(device time from the first forward to the last fold+Adam of those K steps, us per step)", "", K, f"{span / K:.2f}", "", ""])
 open(f"profiles/{rnd}_bench_line_under_rocprof.json", "w").write(line)
 bench_line = json.loads(line)
 
@@ -106,4 +138,4 @@ json.dump({"what": "spmm_lds_kernel (layer-1 aggregation, forward + backward lau
            "csrc_sha": sha, "method": method, "by_batch": sweep}, open(f"profiles/{rnd}_spmm_batch_sweep.json", "w"), indent=1)
 for k, v in sorted(out.items()):
     print(k.ljust(70), {a: round(b) for a, b in v.items()})
-print(open(f"profiles/{rnd}_bench_kernel_stats_by_grid.csv").read()[:2500])
+print(open(f"profiles/{rnd}_bench_kernel_stats_timed_region.csv").read())
