@@ -1045,7 +1045,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(pkg):
 def test_bench_single_rank_over_rccl(pkg):
     """RCCL itself on the one GPU a test box has: GCN_MAXCUT_DP_SINGLE_RANK=1 makes a world of ONE rank run the
     data-parallel step sequence over backend "nccl" - communicator set-up, replica broadcast, the [gradient | loss]
-    all-reduce on the launch stream between replayed hipGraphs (captured while RCCL's watchdog thread is alive).
+    all-reduce on the launch stream between eager launches (the default; GCN_MAXCUT_DP_GRAPHS=1 replays hipGraphs there).
     The loss must be the one the single-GPU fused step reaches after the same number of steps."""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
