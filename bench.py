@@ -364,19 +364,22 @@ def main():
         keys = list(dataset)
         prev = lib.gmc_set_fuse(0)
         for B in (1, 20, min(160, gpg), 1024):
-            sub = {i: dataset[keys[i % len(keys)]] for i in range(B)}
-            net_b, embed_b, opt_b = fresh_model()
-            tr_b = T.FusedTrainer(net_b, opt_b, cfg, graphs_per_step=B, local_shard=True)
-            steps_b = 10 if B >= 1024 else 40
-            _m, kb, _w = probed(tr_b, sub, 5, steps_b)
-            durs = [ms for tag in ("agg_fwd", "agg_bwd") for ms in kb.get(tag, [])]
-            alg = tr_b._batches[0].spmm_bytes(tr_b.eng.Fp)
-            dur = float(np.mean(durs)) * 1e-3
-            by_batch[str(B)] = {"rows": tr_b._batches[0].R, "algorithmic_bytes_per_launch": alg, "mean_launch_us": dur * 1e6,
-                                "achieved_GBps": alg / dur / 1e9, "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
-                                "workgroups": tr_b._batches[0].B * lib_groups(pkg, tr_b._batches[0], tr_b.eng.Fp),
-                                "launches": len(durs)}
-            del tr_b, net_b, embed_b, opt_b, sub
+            try:   # (an extra: e.g. an allocation failure at B = 1024 must not cost the run its headline)
+                sub = {i: dataset[keys[i % len(keys)]] for i in range(B)}
+                net_b, embed_b, opt_b = fresh_model()
+                tr_b = T.FusedTrainer(net_b, opt_b, cfg, graphs_per_step=B, local_shard=True)
+                steps_b = 10 if B >= 1024 else 40
+                _m, kb, _w = probed(tr_b, sub, 5, steps_b)
+                durs = [ms for tag in ("agg_fwd", "agg_bwd") for ms in kb.get(tag, [])]
+                alg = tr_b._batches[0].spmm_bytes(tr_b.eng.Fp)
+                dur = float(np.mean(durs)) * 1e-3
+                by_batch[str(B)] = {"rows": tr_b._batches[0].R, "algorithmic_bytes_per_launch": alg, "mean_launch_us": dur * 1e6,
+                                    "achieved_GBps": alg / dur / 1e9, "frac": alg / dur / 1e9 / HBM_PEAK_GBS,
+                                    "workgroups": tr_b._batches[0].B * lib_groups(pkg, tr_b._batches[0], tr_b.eng.Fp),
+                                    "launches": len(durs)}
+                del tr_b, net_b, embed_b, opt_b, sub
+            except Exception as e:   # noqa: BLE001
+                by_batch[str(B)] = {"error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.empty_cache()
         lib.gmc_set_fuse(prev)
         note("SpMM batch sweep done")
@@ -389,31 +392,40 @@ def main():
         for name, kind, par, base, what in extra_defs:
             gl = dict(enumerate(made[off:off + n_other]))
             off += n_other
-            ds_o = extend(gl, {i: terminals_of(n, base + i) for i in gl})
-            net_o, embed_o, opt_o = fresh_model()
-            tr_o = T.FusedTrainer(net_o, opt_o, cfg, graphs_per_step=len(ds_o), local_shard=True)
-            k_o = max(20, args.steps // 2)
-            km_o, _by, _w = probed(tr_o, ds_o, 40, k_o)
-            dt_o, loss_o = timed(tr_o, ds_o, 20, k_o)
-            b0 = tr_o._batches[0]
-            other[name] = {
-                "workload": what, "ms_per_step": 1e3 * dt_o / k_o, "value": k_o * len(ds_o) / EPOCH_GRAPHS / dt_o,
-                "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)", "steps": k_o,
-                "kernels_us": {k: round(1e3 * v, 2) for k, v in sorted(km_o.items())},
-                "directed_edges": b0.nnz, "max_degree": b0.host.max_degree, "table_slots": b0.host.ell_width,
-                "live_slots": b0.host.ell_slots,
-                "overflow_blocks": int(b0.host.ovf_ptr[-1]) if b0.host.ovf_ptr is not None else 0,
-                "last_loss": loss_o, "parity": parity_gate(pkg, T, net_o, ds_o, n_graphs=1)}
-            net_o.train()
+            try:   # (an extra: must not cost the run its headline)
+                ds_o = extend(gl, {i: terminals_of(n, base + i) for i in gl})
+                net_o, embed_o, opt_o = fresh_model()
+                tr_o = T.FusedTrainer(net_o, opt_o, cfg, graphs_per_step=len(ds_o), local_shard=True)
+                k_o = max(20, args.steps // 2)
+                km_o, _by, _w = probed(tr_o, ds_o, 40, k_o)
+                dt_o, loss_o = timed(tr_o, ds_o, 20, k_o)
+                b0 = tr_o._batches[0]
+                other[name] = {
+                    "workload": what, "ms_per_step": 1e3 * dt_o / k_o, "value": k_o * len(ds_o) / EPOCH_GRAPHS / dt_o,
+                    "unit": f"epochs/s (1 epoch = {EPOCH_GRAPHS} graphs)", "steps": k_o,
+                    "kernels_us": {k: round(1e3 * v, 2) for k, v in sorted(km_o.items())},
+                    "directed_edges": b0.nnz, "max_degree": b0.host.max_degree, "table_slots": b0.host.ell_width,
+                    "live_slots": b0.host.ell_slots,
+                    "overflow_blocks": int(b0.host.ovf_ptr[-1]) if b0.host.ovf_ptr is not None else 0,
+                    "overflow_blocks_of_the_fullest_graph": b0.host.ovf_max_blocks,
+                    "last_loss": loss_o, "parity": parity_gate(pkg, T, net_o, ds_o, n_graphs=1)}
+                del tr_o, net_o, embed_o, opt_o, ds_o
+            except Exception as e:   # noqa: BLE001
+                other[name] = {"workload": what, "error": f"{type(e).__name__}: {e}"[:300]}
             note(f"other workload {name} done")
-            del tr_o, net_o, embed_o, opt_o, ds_o, gl
+            del gl
             torch.cuda.empty_cache()
     del made
 
     # data-parallel step sequence at the strong split's shard sizes, ONE rank over RCCL (N = 1 runs only)
     dp_profile = None
     if not dp and args.mode == "batched" and not args.no_dp_profile and not args.no_probe:
-        dp_profile = dp_shard_profile(args, pkg, T, cfg, dataset, fresh_model, timed, probed)
+        try:   # (an extra: whatever goes wrong in it must not cost the run its headline)
+            dp_profile = dp_shard_profile(args, pkg, T, cfg, dataset, fresh_model, timed, probed)
+        except Exception as e:   # noqa: BLE001
+            dp_profile = {"error": f"{type(e).__name__}: {e}"[:400]}
+            if dist.is_initialized():
+                dist.destroy_process_group()
         note("data-parallel shard profile done")
 
     trainer.allow_graph = True

@@ -295,7 +295,9 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
-            float4 u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
+            float4 u;
+            if constexpr (ovf) u = gather_ids8_halves<FS>(bufA, idr[k], q);   // (see lds_tile.h)
+            else u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
         }
@@ -345,6 +347,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             if (k < ACC) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
                 if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
+                else if constexpr (ovf) acc[k] += gmc::f4v(gather_ids8_halves<FS>(bufB, idr[k], q));
                 else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
                 // the sum is needed HERE (its only user is the store after the graph loop: left alone the
                 // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)

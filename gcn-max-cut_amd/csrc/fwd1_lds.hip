@@ -89,7 +89,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
             // reload in front of each piece comes with s_waitcnt vmcnt(0) - a wait for every H store of the previous
             // gather before the next tile's DMA may even start (that, not the hub rows, cost the OVF forward 2x)
             if constexpr (ovf) asm volatile("" : "+v"(lr));
-            dma_tile<FS, ACC>(a.X + off, a.x_rs, n, true, lr, bufA);
+            dma_tile<FS, ACC, false, ovf>(a.X + off, a.x_rs, n, true, lr, bufA);
         };
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
@@ -176,8 +176,10 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     if (k + 1 < ACC) ids = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
                     // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
                     const int lc = min(l, n - 1);
-                    float4 t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
-                                      : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
+                    float4 t;
+                    if constexpr (ovf && !HAS_VAL) t = gather_ids8_halves<FS>(bufA, cur, q);   // (see lds_tile.h)
+                    else t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
+                                    : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
                     reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
@@ -254,7 +256,9 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
-                    const gmc::v4f h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
+                    gmc::v4f h;
+                    if constexpr (ovf) h = gmc::f4v(gather_ids8_halves<FS>(bufB, cur, q));
+                    else h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
                     if (!later) emit(k, h);
                 } else {
                     const gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));

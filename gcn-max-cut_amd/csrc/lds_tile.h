@@ -183,11 +183,15 @@ __device__ __forceinline__ void loop_syncthreads() {
     else __syncthreads();
 }
 
-template <int FS, int ACC, bool NT = false>
+// FRESH: derive the wave's LDS destination from the thread id anew on every call (kernels under register pressure:
+// hoisted out of the slice loop the value is spilled, and its reload in front of the first piece is a vmcnt(0) wait)
+template <int FS, int ACC, bool NT = false, bool FRESH = false>
 __device__ __forceinline__ void dma_tile(const float *src_q, long rs, int n, bool col_on, int lrow, float *tile) {
     constexpr int kRowsPerPass = kThreads / (FS / 4);
     const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float *)tile;
-    const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (threadIdx.x & ~63u)));
+    unsigned tid = threadIdx.x;
+    if (FRESH) asm volatile("" : "+v"(tid));
+    const unsigned wave_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(base + 16u * (tid & ~63u)));
 #pragma unroll
     for (int k = 0; k < ACC; ++k) {
         const int l = lrow + k * kRowsPerPass;
@@ -227,12 +231,69 @@ __device__ __forceinline__ void read8(const float *tile, int q, unsigned row_byt
     }
 }
 
+// four tile rows named by two packed id pairs (the 16-slot flavours read a row's slots four at a time: with eight
+// rows of reads in flight next to everything else those kernels hold, the compiler spilled their staging registers
+// right behind the loads - a vmcnt wait in the shadow of the tile DMA - and reloaded values inside the gathers)
+template <int NS4>
+__device__ __forceinline__ void read4(const float *tile, int q, unsigned row_bytes, unsigned pk0, unsigned pk1, float4 (&x)[4]) {
+    static_assert(NS4 >= 1 && NS4 <= 4, "slots of one half block");
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    using lds_f4 = __attribute__((address_space(3))) const v4f;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
+    const unsigned pk[2] = {pk0, pk1};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        unsigned lo, hi;
+        if (2 * j >= NS4) break;
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(lo) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+        const v4f a = *(lds_f4 *)(size_t)lo;
+        x[2 * j] = make_float4(a.x, a.y, a.z, a.w);
+        if (2 * j + 1 < NS4) {
+            asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(pk[j]), "s"(row_bytes), "v"(base));
+            const v4f b = *(lds_f4 *)(size_t)hi;
+            x[2 * j + 1] = make_float4(b.x, b.y, b.z, b.w);
+        }
+    }
+}
+
 // sum over the row's first NS of W neighbour slots (slot order, padding -> zero row) from the LDS tile
 template <int FS, int W, bool HAS_VAL, int NS = W>
 __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned short *nb, const float *wrow,
                                              int l, int q) {
     static_assert((W == 8 && (NS == 7 || NS == 8)) || (W == 16 && NS > 8 && NS <= 16), "live slots of the table");
     float4 acc = gmc::f4_zero();
+    if constexpr (W == 16) {   // four slots at a time
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            constexpr int kDummy = 0; (void)kDummy;
+            const int live = NS - 4 * h >= 4 ? 4 : (NS - 4 * h > 0 ? NS - 4 * h : 0);
+            if (live <= 0) break;
+            const uint2 ids = *reinterpret_cast<const uint2 *>(nb + (long)l * W + h * 4);
+            float4 x[4];
+            if (live == 4) read4<4>(tile, q, FS * 4, ids.x, ids.y, x);
+            else if (live == 3) read4<3>(tile, q, FS * 4, ids.x, ids.y, x);
+            else if (live == 2) read4<2>(tile, q, FS * 4, ids.x, ids.y, x);
+            else read4<1>(tile, q, FS * 4, ids.x, ids.y, x);
+            if (HAS_VAL) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(wrow + h * 4);
+                const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < live) gmc::f4_fma(acc, w[u], x[u]);
+            } else if (h == 0) {
+                acc = x[3];   // (NS > 8: the first half block is always full) last read first: one wait per half block
+#pragma unroll
+                for (int u = 2; u >= 0; --u) gmc::f4_add(acc, x[u]);
+            } else {
+#pragma unroll
+                for (int u = 3; u >= 0; --u)
+                    if (u < live) gmc::f4_add(acc, x[u]);
+            }
+            // keep the half blocks apart: left alone the scheduler batches all sixteen reads again
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
+        }
+        return acc;
+    }
 #pragma unroll
     for (int blk = 0; blk < W / 8; ++blk) {
         constexpr int kFirst = NS < 8 ? NS : 8;
@@ -303,7 +364,9 @@ inline bool ovf_fits(int n_max, int W, int FS, int max_blocks) {
     return true;
 }
 __device__ __forceinline__ OvfLds ovf_lds(const float *lds_base, int own_bytes, int n_max, int cap) {
-    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)lds_base + (unsigned)own_bytes;
+    // (wave-uniform values: kept in scalar registers)
+    const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane(
+        (int)((unsigned)(size_t)(__attribute__((address_space(3))) const float *)lds_base + (unsigned)own_bytes));
     return OvfLds{base, base + (unsigned)ovf_desc_bytes(n_max), cap};
 }
 // set up desc[] and blocks[] for the graph at rows [r0, r0 + n); callers separate this from the gathers that read the
@@ -396,6 +459,23 @@ __device__ __forceinline__ gmc::v4f gather_ids8_pk(const float *tile, const uint
         hi += (gmc::v2f){x[u].z, x[u].w};
     }
     return (gmc::v4f){lo.x, lo.y, hi.x, hi.y};
+}
+
+// gather_ids8 for unit weights with the row's eight slots read four at a time (two half blocks kept apart): what the
+// OVF flavours of the 8-slot kernels use - they carry a few more live values than the plain kernels, and with eight
+// rows of reads in flight that was enough to push values into scratch inside the gathers.
+template <int FS>
+__device__ __forceinline__ float4 gather_ids8_halves(const float *tile, const uint4 ids, int q) {
+    float4 x[4];
+    read4<4>(tile, q, FS * 4, ids.x, ids.y, x);
+    float4 acc = x[3];
+#pragma unroll
+    for (int u = 2; u >= 0; --u) gmc::f4_add(acc, x[u]);
+    asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w));
+    read4<4>(tile, q, FS * 4, ids.z, ids.w, x);
+#pragma unroll
+    for (int u = 3; u >= 0; --u) gmc::f4_add(acc, x[u]);
+    return acc;
 }
 
 // Slice width for graphs of up to n_max nodes with W neighbour slots: the widest slice whose

@@ -166,3 +166,21 @@ def test_reference_schedule_on_mixed_degrees(pkg):
         ref = sum(float(ct.step([c])[0]) for c in csrs)
         got = T.train_single_epoch(ds, net, opt, embed, cfg)
         assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), (epoch, got, ref)
+
+
+@pytest.mark.parametrize("hidden,build", [
+    (128, lambda: {0: R.regular_graph(530, 12, 41), 1: R.regular_graph(520, 11, 42)}),          # 16 slots, FS = 32, 8 rows per thread
+    (256, lambda: {0: R.regular_graph(270, 12, 43), 1: R.regular_graph(262, 9, 44)}),           # 16 slots, FS = 64, 8 rows per thread
+    (128, lambda: {0: with_hub(530, 7, 45, 33), 1: R.regular_graph(520, 6, 46)}),               # 8 slots + overflow, FS = 32, 8 rows
+    (256, lambda: {0: with_hub(270, 7, 47, 29), 1: R.regular_graph(262, 8, 48)}),               # 8 slots + overflow, FS = 64, 8 rows
+    (128, lambda: {0: with_hub(530, 12, 49, 45), 1: R.regular_graph(520, 11, 50)}),             # 16 slots + overflow, FS = 32, 8 rows
+    (64, lambda: {0: gnp(270, 0.045, 51), 1: gnp(200, 0.05, 52)}),                              # 16 slots + overflow, FS = 64, 8 rows
+])
+def test_eight_rows_per_thread_flavours_of_the_new_paths(pkg, hidden, build):
+    """Graphs just below the LDS capacity of a slice width run 8 rows per thread (the ACC = 8 instantiations): the
+    16-slot, live-slot and overflow flavours of round 3 at those shapes, fused, against the oracle."""
+    T, cfg, net, embed, opt, params = model(pkg, hidden)
+    graphs = build()
+    ds = util.dataset_of(graphs, terms_for(graphs))
+    eng, tags = util.check_step_against_oracle(pkg, net, ds, params)
+    assert set(tags) == FUSED, tags
