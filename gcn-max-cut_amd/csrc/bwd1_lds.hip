@@ -190,6 +190,20 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #endif
     constexpr int KREG = (!HAS_VAL && !OVF) ? (GMC_BWD1_KREG < ACC ? GMC_BWD1_KREG : ACC) : 0;
     float4 hreg[KREG > 0 ? KREG : 1];
+    // RECYCLE (default with KREG > 0): NO LDS-DMA for the tile at all - the cells beyond the first KREG are loaded into
+    // the staging registers of cells already transformed: cell j >= KREG into slot j % KREG, behind transform(j - KREG),
+    // which rides between the rows of gather #2 (the data of the early cells IS there by then, unlike in the
+    // interleaving experiment above).  Every wait for H data is then the compiler's own counted vmcnt on loads it
+    // knows; the transform takes its cell from registers (no ds_read), the tile never lands raw in LDS.
+#ifndef GMC_BWD1_RECYCLE
+#define GMC_BWD1_RECYCLE 1
+#endif
+    constexpr bool kRecycle = GMC_BWD1_RECYCLE && KREG > 0;
+    auto load_cell = [&](int slot, int k, int r0n, int nn) {
+        const int l = min(lrow + k * kRowsPerPass, nn - 1);
+        const gmc::v4f v = __builtin_nontemporal_load(reinterpret_cast<const gmc::v4f *>(Hs + (long)(r0n + l) * FS + 4 * q));
+        hreg[slot] = make_float4(v.x, v.y, v.z, v.w);
+    };
     auto load_hreg = [&](int r0n, int nn) {
 #pragma unroll
         for (int k = 0; k < KREG; ++k) {
@@ -205,14 +219,18 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     if constexpr (ovf) ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
     // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
     // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
+    // two steps: the loads (nothing uses their data - a use right behind a load is a vmcnt wait, and one placed in the
+    // shadow of the tile DMA waits for the tile), then, once they have landed, the pad ids for the rows past n
     auto load_ids = [&](int r0, int n) {
+#pragma unroll
+        for (int k = 0; k < ACC; ++k)
+            idr[k] = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(lrow + k * kRowsPerPass, n - 1)) * W);
+    };
+    auto pad_ids = [&](int n) {
         const unsigned pad = (unsigned)n * 0x10001u;
 #pragma unroll
-        for (int k = 0; k < ACC; ++k) {
-            const int l = lrow + k * kRowsPerPass;
-            const uint4 v = *reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + min(l, n - 1)) * W);
-            idr[k] = l < n ? v : make_uint4(pad, pad, pad, pad);
-        }
+        for (int k = 0; k < ACC; ++k)
+            if (lrow + k * kRowsPerPass >= n) idr[k] = make_uint4(pad, pad, pad, pad);
     };
     auto zero_pads = [&](float *buf, int n) {  // the zero rows n..n+3 the padding entries point at
         if (threadIdx.x < kPadRows * FS) buf[n * FS + threadIdx.x] = 0.f;
@@ -235,7 +253,8 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         const int l = lrow + k * kRowsPerPass;
         float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
         if (l >= n) rck = gmc::f4_zero();
-        transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck, k < KREG ? &hreg[k] : nullptr);
+        const bool from_reg = kRecycle || k < KREG;
+        transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck, from_reg ? &hreg[KREG > 0 ? k % KREG : 0] : nullptr);
     };
     // wait until piece k of the tile DMA this wave issued `pieces` pieces of has landed (they retire in issue order;
     // younger loads of the gather only make the wait longer than needed, never shorter)
@@ -259,7 +278,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     int nn = g0 + 1 < g1 ? a.b.goff[g0 + 2] - (r0 + n) : 0;   // size of graph g+1 (0: none)
     dma_row_consts(a.GY2, r0, n, gy0);
-    fetch_tile(r0, n, KREG);
+    if (!kRecycle) fetch_tile(r0, n, KREG);
     load_hreg(r0, n);
     load_ids(r0, n);
     if constexpr (ovf) ovf_setup(a.b, r0, n, ol);
@@ -269,14 +288,25 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     STAMP_DECL;
     MARK(1);
 #pragma unroll
-    for (int k = 0; k < ACC; ++k) transform(k, n, gy0);   // first graph: nothing to hide behind
+    for (int k = 0; k < ACC; ++k) {   // first graph: nothing to hide behind
+        transform(k, n, gy0);
+        if (kRecycle && k + KREG < ACC) load_cell(k % KREG, k + KREG, r0, n);
+    }
     for (int g = g0; g < g1; ++g) {
         const int cur = (g - g0) & 1;
         const float *gyl = cur ? gy1 : gy0;
         float *gyn = cur ? gy0 : gy1;
         const int r0n = r0 + n;                                              // == goff[g + 1]
-        const int n2 = g + 2 < g1 ? a.b.goff[g + 3] - (r0n + nn) : 0;        // size of graph g+2 (0: none)
+        // (size of graph g+2, 0: none - read at the END of the iteration, through the scalar cache: see sload)
         STAMP(0);
+        // The neighbour ids of graph g were requested behind gather #2 of graph g-1 and have landed under the wait
+        // for the tile (below).  Tell the compiler HERE - an empty asm that reads them makes it place its own vmcnt for
+        // those loads at this point, where nothing else is in flight; left to the first use in gather #1 its wait
+        // (a vmcnt(0) at the join of the branch below) also covered the row-constant DMA issued just before the
+        // barrier, i.e. every graph paid that DMA's latency in front of barrier A.
+#pragma unroll
+        for (int k = 0; k < ACC; ++k) asm volatile("" : "+v"(idr[k].x), "+v"(idr[k].y), "+v"(idr[k].z), "+v"(idr[k].w));
+        pad_ids(n);
         // row constants of graph g+1 into the other buffer (its last reader, transform(g-1), is two barriers back):
         // published by barrier B, read by transform(g+1) behind it
         if (nn > 0 && !ABL(1)) dma_row_consts(a.GY2, r0n, nn, gyn);
@@ -321,7 +351,9 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         STAMP(4);  // barrier B: U tile complete, bufA free, next row constants visible
         // (3) next graph's H tile streams into bufA while (4) gathers from bufB and (1') turns the landed pieces into Gs
         int pieces = 0;   // tile DMA instructions this wave issues for graph g+1 (wave-uniform)
-        if (nn > 0 && !ABL(1)) {
+        if (kRecycle) {
+            if (nn > 0) zero_pads(bufA, nn);
+        } else if (nn > 0 && !ABL(1)) {
             fetch_tile(r0n, nn, KREG);
             zero_pads(bufA, nn);
 #pragma unroll
@@ -345,6 +377,10 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC + kLead; ++k) {
             if (k < ACC) {
+                if (kRecycle && nn > 0) {   // cell k is in registers: turn it into Gs AHEAD of row k of the gather, then
+                    transform(k, nn, gyn);  // send for the cell that recycles its registers (longest possible shadow)
+                    if (k + KREG < ACC) load_cell(k % KREG, k + KREG, r0n, nn);
+                }
                 const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
                 if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
                 else if constexpr (ovf) acc[k] += gmc::f4v(gather_ids8_halves<FS>(bufB, idr[k], q));
@@ -352,8 +388,11 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 // the sum is needed HERE (its only user is the store after the graph loop: left alone the
                 // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
                 asm volatile("" : "+v"(acc[k]));
+                // plain order (kLead == ACC): gather #2 is done with the ids - request graph g+1's now, so that they
+                // travel under the wait for the tile and the transforms instead of in front of barrier A
+                if (k == ACC - 1 && kLead == ACC && nn > 0) load_ids(r0n, nn);
             }
-            if (k >= kLead && nn > 0) {
+            if (!kRecycle && k >= kLead && nn > 0) {
                 const int j = k - kLead;
                 wait_piece(j, pieces);
                 __builtin_amdgcn_sched_barrier(0);   // the transform's LDS read must not move above the wait
@@ -368,9 +407,9 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             }
         }
         STAMP(6);  // gather 2 + transform of the next graph
-        dma_wait();
+        if (!kRecycle) dma_wait();
         STAMP(7);
-        if (nn > 0) load_ids(r0n, nn);   // first needed after barrier A
+        if (kLead != ACC && nn > 0) load_ids(r0n, nn);   // (interleaved tuning builds: the ids are in use until here)
         if constexpr (ovf) {
             if (nn > 0) {   // every wave is done with this graph's descriptors / blocks before they are rewritten
                 loop_barrier();
@@ -378,6 +417,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             }
         }
         STAMP(9);
+        const int n2 = g + 2 < g1 ? sload(a.b.goff, g + 3) - (r0n + nn) : 0;
         r0 = r0n; n = nn; nn = n2;
     }
     STAMP_FLUSH;
@@ -473,7 +513,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     __syncthreads();
     for (int g = g0; g < g1; ++g) {
         const int r0n = r0 + n;                                        // == goff[g + 1]
-        const int nn = g + 1 < g1 ? a.b.goff[g + 2] - r0n : n;         // next graph's size (used after gather 1)
+        const int nn = g + 1 < g1 ? sload(a.b.goff, g + 2) - r0n : n;  // next graph's size (used after gather 1; scalar cache: see sload)
         float dv[ACC];
         // (1) H -> Gs in place + column partials (row constants: staged in bufB with the table)
 #pragma unroll

@@ -93,6 +93,16 @@ struct TileArgs {
     int own_lds;         //       ... which end at this byte offset
 };
 
+// A graph offset (or any wave-uniform int of a read-only table) through the SCALAR cache.  Inside the tile loops the
+// compiler will not use s_load for such a read: the LDS-DMA's inline asm clobbers memory, so it falls back to a VECTOR
+// load - whose wait is a vmcnt wait, i.e. a wait for whatever tile or table traffic is in flight (round 2's "loop top:
+// 9-12 % of the backward's cycles").  The tables read this way are never written by a kernel.
+__device__ __forceinline__ int sload(const int32_t *p, int index) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p + index) : "memory");
+    return v;
+}
+
 // block -> (graph, group): all groups of a graph on one XCD (blocks are dealt round-robin
 // over the 8 XCDs), consecutive in that XCD's dispatch order.
 __device__ __forceinline__ void tile_of(int b, int B, int S, int &g, int &s) {
