@@ -54,26 +54,32 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16*4] *
 
 // neighbours of local row l: through the 16-byte ELL row (one load, padding ids >= n hit zeroed
 // slots) when the batch carries it, else the CSR row
-template <bool ELL, typename F>
+// W: slots of the ELL table as a compile-time constant (8 or 16; 0 = CSR walk).  With a run-time width the unpacked
+// ids lived in scratch (48 B per lane): three neighbour loops per row, each going through vector memory.
+template <int W, typename F>
 __device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l, int n, bool cached, const uint4 c0,
                                                const uint4 c1, F &&f) {
-    if (ELL) {  // cached: the row's ids are already in registers (c0, c1) - no global read
-        const int W = b.ell_width;
+    if constexpr (W > 0) {  // cached: the row's ids are already in registers (c0, c1) - no global read
         const uint4 *row = reinterpret_cast<const uint4 *>(b.ell + (long)(r0 + l) * W);
+#pragma unroll
         for (int blk = 0; blk < W / 8; ++blk) {
             const uint4 ids = cached ? (blk == 0 ? c0 : c1) : row[blk];
-            const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
-                                    ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+            const unsigned pk[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-            for (int u = 0; u < 8; ++u) f((int)id[u], b.ell_vals ? b.ell_vals[(long)(r0 + l) * W + blk * 8 + u] : 1.0f);
+            for (int u = 0; u < 8; ++u) {
+                const unsigned id = (u & 1) ? pk[u >> 1] >> 16 : pk[u >> 1] & 0xffffu;
+                f((int)id, b.ell_vals ? b.ell_vals[(long)(r0 + l) * W + blk * 8 + u] : 1.0f);
+            }
         }
         if (b.ovf_ptr) {  // rows of hub degree: their overflow blocks (padding ids hit the zeroed slots as well)
             for (int blk = b.ovf_ptr[r0 + l]; blk < b.ovf_ptr[r0 + l + 1]; ++blk) {
                 const uint4 ids = reinterpret_cast<const uint4 *>(b.ovf_ids)[blk];
-                const unsigned id[8] = {ids.x & 0xffffu, ids.x >> 16, ids.y & 0xffffu, ids.y >> 16,
-                                        ids.z & 0xffffu, ids.z >> 16, ids.w & 0xffffu, ids.w >> 16};
+                const unsigned pk[4] = {ids.x, ids.y, ids.z, ids.w};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) f((int)id[u], b.ovf_vals ? b.ovf_vals[8l * blk + u] : 1.0f);
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned id = (u & 1) ? pk[u >> 1] >> 16 : pk[u >> 1] & 0xffffu;
+                    f((int)id, b.ovf_vals ? b.ovf_vals[8l * blk + u] : 1.0f);
+                }
             }
         }
     } else {
@@ -82,8 +88,9 @@ __device__ __forceinline__ void for_neighbours(const gmc_batch &b, int r0, int l
     (void)n;
 }
 
-template <bool ELL>
+template <int W>
 __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
+    constexpr bool ELL = W > 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int g = blockIdx.x;
     const int r0 = a.b.goff[g];
@@ -105,9 +112,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     if (l0 < n) {
         cd = a.b.dinv[r0 + l0];
         if (ELL) {
-            const uint4 *row = reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + l0) * a.b.ell_width);
+            const uint4 *row = reinterpret_cast<const uint4 *>(a.b.ell + (long)(r0 + l0) * W);
             cid0 = row[0];
-            if (a.b.ell_width > 8) cid1 = row[1];
+            if (W > 8) cid1 = row[1];
         }
     }
     const float bias0 = a.b2[0], bias1 = a.b2[1], bias2 = a.b2[2];
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
         float z0 = 0.f, z1 = 0.f, z2 = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2]; });
+        for_neighbours<W>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { z0 += sA[3 * c]; z1 += sA[3 * c + 1]; z2 += sA[3 * c + 2]; });
         const float d = l == l0 ? cd : a.b.dinv[r];
         z0 = fmaf(z0, d, bias0); z1 = fmaf(z1, d, bias1); z2 = fmaf(z2, d, bias2);
         const float m = fmaxf(z0, fmaxf(z1, z2));
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         const int r = r0 + l;
         const int me = sS[l];
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, cut = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float w) {
+        for_neighbours<W>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float w) {
             const int sc = sS[c];  // padding slots carry class 3: no contribution
             g0 += sc == 0 ? w : 0.f; g1 += sc == 1 ? w : 0.f; g2 += sc == 2 ? w : 0.f;
             cut += (sc != me && sc != 3) ? w : 0.f;
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
         const int r = r0 + l;
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-        for_neighbours<ELL>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
+        for_neighbours<W>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
         *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, l == l0 ? cd : a.b.dinv[r]);
     }
 }
@@ -291,18 +298,17 @@ int gmc_head_launch(const gmc_batch *batch, const float *Z0, int32_t z_parts, co
     if (batch->B == 0) return GMC_OK;
     HeadArgs a{*batch, Z0, z_parts, b2, C, P, S, loss, GY2, db2part, tick};
     const size_t lds = sizeof(float) * (7 * ((size_t)batch->n_max + 4) + 64);
-    const bool ell = batch->ell != nullptr && batch->ell_width > 0;
+    const int w = (batch->ell != nullptr && (batch->ell_width == 8 || batch->ell_width == 16)) ? batch->ell_width : 0;
+    const void *fn = w == 8 ? reinterpret_cast<const void *>(head_kernel<8>)
+                   : w == 16 ? reinterpret_cast<const void *>(head_kernel<16>) : reinterpret_cast<const void *>(head_kernel<0>);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(ell ? reinterpret_cast<const void *>(head_kernel<true>)
-                                               : reinterpret_cast<const void *>(head_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     GmcProbeScope probe(GMC_K_HEAD, stream);
-    if (ell) hipLaunchKernelGGL(head_kernel<true>, dim3(batch->B), dim3(kHeadThreads), lds,
-                                stream, a);
-    else hipLaunchKernelGGL(head_kernel<false>, dim3(batch->B), dim3(kHeadThreads), lds,
-                       stream, a);
+    if (w == 8) hipLaunchKernelGGL(head_kernel<8>, dim3(batch->B), dim3(kHeadThreads), lds, stream, a);
+    else if (w == 16) hipLaunchKernelGGL(head_kernel<16>, dim3(batch->B), dim3(kHeadThreads), lds, stream, a);
+    else hipLaunchKernelGGL(head_kernel<0>, dim3(batch->B), dim3(kHeadThreads), lds, stream, a);
     GMC_LAUNCH_CHECK();
     return GMC_OK;
 }
