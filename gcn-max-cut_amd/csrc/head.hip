@@ -42,13 +42,17 @@ __device__ __forceinline__ void block_sum4(float (&v)[4], float *red /* [16*4] *
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const int nw = blockDim.x >> 6;
+        // every wave's partial is requested before the first add (64 reads in flight instead of 64 dependent
+        // scalar reads: ~2 us of wave 0's - and so of the launch's - critical path); same ascending order of the adds
+        float part[kHeadThreads / 64][4];   // (scalar reads: `red` is only 4-byte aligned for odd graph sizes)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float s = 0.f;
-            for (int w = 0; w < nw; ++w) s += red[w * 4 + k];
-            v[k] = s;
-        }
+        for (int w = 0; w < kHeadThreads / 64; ++w)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) part[w][k] = red[w * 4 + k];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kHeadThreads / 64; ++w) { s0 += part[w][0]; s1 += part[w][1]; s2 += part[w][2]; s3 += part[w][3]; }
+        v[0] = s0; v[1] = s1; v[2] = s2; v[3] = s3;
     }
 }
 
@@ -101,7 +105,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     int *sS = reinterpret_cast<int *>(lds + 6 * NP);  // [NP] argmax class
     float *red = lds + 7 * NP;                // [64]
     const bool train = a.GY2 != nullptr;
-    if (a.tick && blockIdx.x == 0 && threadIdx.x == 0) *a.tick += 1;  // nobody reads it during this kernel
+    // nobody reads the counter during this kernel.  A no-return atomic: `*tick += 1` is a load the wave has to wait for
+    // before its store - a memory round trip at the top of block 0's critical path (a one-graph launch IS block 0)
+    if (a.tick && blockIdx.x == 0 && threadIdx.x == 0) (void)__hip_atomic_fetch_add(a.tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     // The kernel is one workgroup per graph and latency-bound: request everything this thread will
     // need from global memory now (its first row's neighbour ids, dinv, the bias), so that the three
