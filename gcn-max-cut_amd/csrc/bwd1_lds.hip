@@ -100,10 +100,7 @@ __device__ __forceinline__ void col_epilogue(const ColState &c, float *red, floa
         colp[4 * (2 * p) + 3] = c.cdb1[p].x; colp[4 * (2 * p + 1) + 3] = c.cdb1[p].y;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int o = 32; o >= Q; o >>= 1) colp[i] += __shfl_xor(colp[i], o, GMC_WAVE);
-    }
+    for (int i = 0; i < 16; ++i) colp[i] = gmc::xor_tree<32, Q>(colp[i]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < Q) {
 #pragma unroll
@@ -442,6 +439,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             const int l = lrow + k * kRowsPerPass;
+            // (default cache policy: non-temporal stores here cost the launch 2.5 us and the fold behind it 0.4 - same-box A/B)
             if (l < a.b.n_max) *reinterpret_cast<float4 *>(a.dw1part + ((long)chunk * a.b.n_max + l) * a.F + f0) = gmc::v4f_f4(acc[k]);
         }
     }

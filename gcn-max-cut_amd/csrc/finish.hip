@@ -10,6 +10,17 @@
 #include "gmc_common.h"
 #include <math.h>
 
+// Diagnostic build only (-DGMC_STAMP): wall-clock entry / exit marks of every block (see head.hip)
+#ifdef GMC_STAMP
+static __device__ unsigned long long g_fstamps[2048 * 2];
+extern "C" int gmc_debug_read_stamps_fin(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fstamps), sizeof(unsigned long long) * n);
+}
+#define FMARK(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) g_fstamps[blockIdx.x * 2 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FMARK(i)
+#endif
+
 namespace {
 
 struct FinishArgs {
@@ -34,39 +45,60 @@ __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v,
     p = p - step_size * (m / (sqrtf(v) / bc2_sqrt + eps));
 }
 
+// R: chunk partials requested per round trip (a power of two >= the number of chunks, at most 16): every load of a
+// round is unconditional (indices past the last chunk re-read the last one and are dropped by a select), so the
+// loop body has no branches for the compiler to sink the adds into - which it did, with a wait behind the first load.
+template <int R>
 __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
-    __shared__ float sh[2];
+    FMARK(0);
     const bool adam = a.param != nullptr;
-    if (adam && threadIdx.x == 0) {
-        const double t = (double)(*a.step_counter);
-        sh[0] = (float)(a.lr / (1.0 - pow(a.beta1, t)));
-        sh[1] = (float)sqrt(1.0 - pow(a.beta2, t));
-    }
-    __syncthreads();
+    // Bias corrections of this step (torch.optim.Adam: step_size = lr / (1 - beta1^t), sqrt(1 - beta2^t), in double).
+    // The launch is 7-11 us long and latency-bound, and two double-precision pow() calls are ~1 us of it: the step
+    // number comes by a SCALAR load requested first of all (its own counter: no vmcnt wait), every lane computes the
+    // corrections for itself (no LDS hand-over, no barrier), and the element loop requests its first element's
+    // p / m / v / partials BEFORE that arithmetic, which then runs in the shadow of the memory round trip.
+    int tstep = 0;
+    if (adam) asm volatile("s_load_dword %0, %1, 0x0" : "=s"(tstep) : "s"(a.step_counter) : "memory");
     const float w1 = (float)(1.0 - a.beta1), b2 = (float)a.beta2, w2 = (float)(1.0 - a.beta2);
-    const float step_size = adam ? sh[0] : 0.f, bc2_sqrt = adam ? sh[1] : 1.f;
     const long nW1 = (long)a.N * a.F, live = (long)a.n_max * a.F;
     const long n4 = nW1 >> 2;  // F % 4 == 0
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += stride) {
-        // every read of the element is requested before the first use: the launch is short and
-        // latency-bound, so it pays one memory round trip, not one per batch of partials
-        float4 p, m, v;
+    const long cs = live >> 2;
+    const long i_first = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    float4 p, m, v, t[R];
+    // reads of one element: p / m / v and the first R chunk partials (rows past n_max: no graph reaches them, gradient 0)
+    auto request = [&](long i) {
         if (adam) {
             p = reinterpret_cast<const float4 *>(a.param)[i];
             m = reinterpret_cast<const float4 *>(a.m)[i];
             v = reinterpret_cast<const float4 *>(a.v)[i];
         }
+        const float4 *src = reinterpret_cast<const float4 *>(a.dw1part) + (i * 4 < live ? i : 0);
+#pragma unroll
+        for (int u = 0; u < R; ++u) t[u] = src[(long)min(u, a.chunks - 1) * cs];
+    };
+    request(min(i_first, n4 - 1));   // (threads beyond the last element re-read it and drop it)
+    float step_size = 0.f, bc2_sqrt = 1.f;
+    if (adam) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tstep) : : "memory");   // (nothing reads tstep before this)
+        const double ts = (double)tstep;
+        step_size = (float)(a.lr / (1.0 - pow(a.beta1, ts)));
+        bc2_sqrt = (float)sqrt(1.0 - pow(a.beta2, ts));
+    }
+    for (long i = i_first; i < n4; i += stride) {
+        if (i != i_first) request(i);
+        const bool has_parts = i * 4 < live;
         float4 g = gmc::f4_zero();
-        if (i * 4 < live) {  // chunk partials, summed in ascending chunk order
+        // chunk partials, summed in ascending chunk order
+#pragma unroll
+        for (int u = 0; u < R; ++u) gmc::f4_add(g, has_parts && u < a.chunks ? t[u] : gmc::f4_zero());
+        if (has_parts) {
             const float4 *src = reinterpret_cast<const float4 *>(a.dw1part) + i;
-            const long cs = live >> 2;
-            for (int c0 = 0; c0 < a.chunks; c0 += 16) {
-                float4 t[16];
+            for (int c0 = R; c0 < a.chunks; c0 += R) {   // (more than 16 chunks)
 #pragma unroll
-                for (int u = 0; u < 16; ++u) t[u] = c0 + u < a.chunks ? src[(long)(c0 + u) * cs] : gmc::f4_zero();
+                for (int u = 0; u < R; ++u) t[u] = src[(long)min(c0 + u, a.chunks - 1) * cs];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) gmc::f4_add(g, t[u]);
+                for (int u = 0; u < R; ++u) gmc::f4_add(g, c0 + u < a.chunks ? t[u] : gmc::f4_zero());
             }
         }
         reinterpret_cast<float4 *>(a.grad)[i] = g;
@@ -109,9 +141,7 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
             for (int k = 0; k < 3; ++k) g[k] += a.db2part[b * 3 + k];
         }
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) g[k] += __shfl_xor(g[k], o, GMC_WAVE);
+        for (int k = 0; k < 3; ++k) g[k] = gmc::wave_sum(g[k]);
         if (threadIdx.x < 3) {
             const float gk = threadIdx.x == 0 ? g[0] : threadIdx.x == 1 ? g[1] : g[2];
             const long idx = nW1 + tail + threadIdx.x;
@@ -121,18 +151,20 @@ __global__ __launch_bounds__(256) void finish_kernel(FinishArgs a) {
         if (a.loss) {  // the batch's loss sum rides in the slot after the gradient (same fixed order)
             float ls = 0.f;
             for (int b = threadIdx.x; b < a.B; b += 64) ls += a.loss[b];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, GMC_WAVE);
+            ls = gmc::wave_sum(ls);
             if (threadIdx.x == 0) a.grad[nW1 + tail + 3] = ls;
         }
     }
+#ifdef GMC_STAMP
+    __builtin_amdgcn_s_waitcnt(0);
+    FMARK(1);
+#endif
 }
 
 __global__ __launch_bounds__(64) void loss_tail_kernel(const float *loss, int B, float *slot) {
     float ls = 0.f;
     for (int b = threadIdx.x; b < B; b += 64) ls += loss[b];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, GMC_WAVE);
+    ls = gmc::wave_sum(ls);
     if (threadIdx.x == 0) *slot = ls;
 }
 
@@ -158,7 +190,11 @@ int gmc_finish_launch(const float *dw1part, const float *colpart, const float *d
     if (blocks < 1) blocks = 1;
     {
         GmcProbeScope probe(GMC_K_FINISH, st);
-        hipLaunchKernelGGL(finish_kernel, dim3((int)blocks), dim3(256), 0, st, a);
+        if (chunks <= 1) hipLaunchKernelGGL(finish_kernel<1>, dim3((int)blocks), dim3(256), 0, st, a);
+        else if (chunks <= 2) hipLaunchKernelGGL(finish_kernel<2>, dim3((int)blocks), dim3(256), 0, st, a);
+        else if (chunks <= 4) hipLaunchKernelGGL(finish_kernel<4>, dim3((int)blocks), dim3(256), 0, st, a);
+        else if (chunks <= 8) hipLaunchKernelGGL(finish_kernel<8>, dim3((int)blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(finish_kernel<16>, dim3((int)blocks), dim3(256), 0, st, a);
         GMC_LAUNCH_CHECK();
     }
     return GMC_OK;

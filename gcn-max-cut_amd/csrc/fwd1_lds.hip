@@ -137,10 +137,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
                 for (int k = 0; k < ACC; ++k) {
                     float z0 = z01[k].x, z1 = z01[k].y, zz = z2[k];
-#pragma unroll
-                    for (int o = Q / 2; o > 0; o >>= 1) {
-                        z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); zz += __shfl_xor(zz, o, GMC_WAVE);
-                    }
+                    z0 = gmc::xor_tree<Q / 2, 1>(z0); z1 = gmc::xor_tree<Q / 2, 1>(z1); zz = gmc::xor_tree<Q / 2, 1>(zz);
                     int l = lrow + k * kRowsPerPass;
                     asm volatile("" : "+v"(l));  // keeps the store addresses out of the slice loop's live set
                     if (q == 0 && l < n) {

@@ -37,12 +37,42 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (GMC_WAVE 
 // wave-uniform value -> SGPR so that dependent loads become scalar loads
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// Butterfly sum over the 64 lanes; every lane gets the total.  Fixed order => deterministic.
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, GMC_WAVE);
+// v[lane] + v[lane ^ O] on the VALU: `__shfl_xor` is a ds_bpermute_b32 - a trip through the LDS pipe the gathers of the
+// tiled kernels live on, ~100 cycles of latency each in the latency-bound ones.  gfx950: v_permlane32_swap /
+// v_permlane16_swap exchange half waves / neighbouring rows of 16, DPP covers the distances inside a row (row_ror:8 IS
+// xor 8; xor 4 = row_shl:4 for lanes 0-3 / 8-11 of a row, row_shr:4 for the others, chosen by the bank mask).  The add
+// is commutative, so every lane gets bitwise what `v + __shfl_xor(v, O)` gave it.
+template <int O>
+__device__ __forceinline__ float xor_add(float v) {
+    static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "lane distance");
+    const unsigned u = __float_as_uint(v);
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    } else if constexpr (O == 4) {
+        unsigned t = __builtin_amdgcn_update_dpp(u, u, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+        t = __builtin_amdgcn_update_dpp(t, u, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+        return v + __uint_as_float(t);
+    } else {
+        constexpr int ctrl = O == 8 ? 0x128 /* row_ror:8 */ : O == 2 ? 0x4e /* quad_perm:[2,3,0,1] */ : 0xb1 /* [1,0,3,2] */;
+        return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, u, ctrl, 0xf, 0xf, false));
+    }
+}
+// the butterfly steps of distance HI, HI/2, ..., LO (powers of two): sum over the lanes that differ in those bits
+template <int HI, int LO>
+__device__ __forceinline__ float xor_tree(float v) {
+    if constexpr (HI >= LO && HI >= 1) {
+        v = xor_add<HI>(v);
+        if constexpr (HI / 2 >= LO && HI / 2 >= 1) v = xor_tree<HI / 2, LO>(v);
+    }
     return v;
 }
+
+// Butterfly sum over the 64 lanes; every lane gets the total.  Fixed order => deterministic.
+__device__ __forceinline__ float wave_sum(float v) { return xor_tree<32, 1>(v); }
 
 // max(x, 0) as ONE v_max_f32 (the C++ forms compile to a canonicalising v_max x,x plus the max)
 __device__ __forceinline__ float relu1(float x) {

@@ -13,6 +13,25 @@
 // Sums run in CSR / fixed tree order: bitwise reproducible.
 #include "gmc_common.h"
 
+// Diagnostic build only (-DGMC_STAMP, `make stamp`): wall-clock marks (s_memrealtime: one 100 MHz counter for the whole
+// chip) of block 0's oldest and youngest wave at the phase boundaries; scratch/seq_stamps.py puts them on one time line
+// with the marks of the other kernels of a one-graph step.  The production library contains none of this.
+#ifdef GMC_STAMP
+static __device__ unsigned long long g_hstamps[2 * 16];
+extern "C" int gmc_debug_read_stamps_head(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hstamps), sizeof(unsigned long long) * n);
+}
+#define HMARK(i)                                                                                         \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == kHeadThreads - 64))                   \
+            g_hstamps[(threadIdx.x ? 16 : 0) + (i)] = __builtin_amdgcn_s_memrealtime();                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define HMARK(i)
+#endif
+
 namespace {
 
 constexpr int kHeadThreads = 1024;
@@ -96,6 +115,7 @@ template <int W>
 __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     constexpr bool ELL = W > 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    HMARK(0);
     const int g = blockIdx.x;
     const int r0 = a.b.goff[g];
     const int n = a.b.goff[g + 1] - r0;
@@ -157,7 +177,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
     }
     if (threadIdx.x < 12) sA[3 * n + threadIdx.x] = 0.f;
     if (threadIdx.x < 4) sS[n + threadIdx.x] = 3;  // a class no node has
+    HMARK(1);
     __syncthreads();
+    HMARK(2);
 
     // phase 1: aggregate, bias, softmax, override, argmax
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
@@ -184,7 +206,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         sS[l] = s;
         if (a.S) a.S[r] = s;
     }
+    HMARK(3);
     __syncthreads();
+    HMARK(4);
 
     // phase 2: cut value (+ GP, softmax backward, dinv*GZ when training)
     float acc[4] = {0.f, 0.f, 0.f, 0.f};  // cut2, db2[0..2]
@@ -208,7 +232,9 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
             sA[3 * l] = z0 * d; sA[3 * l + 1] = z1 * d; sA[3 * l + 2] = z2 * d;
         }
     }
+    HMARK(5);
     block_sum4(acc, red);  // contains a __syncthreads(): sA writes are visible after it
+    HMARK(6);
     if (threadIdx.x == 0) {
         // one system-scope store: `loss` may be pinned host memory the caller watches (the value is final here,
         // long before the launch - let alone a graph of launches - ends)
@@ -218,6 +244,7 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         }
     }
     if (!train) return;
+    HMARK(7);
 
     // phase 3: GY2 = A @ (dinv o GZ)   (A symmetric: A^T == A)
     for (int l = threadIdx.x; l < n; l += blockDim.x) {
@@ -226,6 +253,11 @@ __global__ __launch_bounds__(kHeadThreads) void head_kernel(HeadArgs a) {
         for_neighbours<W>(a.b, r0, l, n, l == l0, cid0, cid1, [&](int c, float) { y0 += sA[3 * c]; y1 += sA[3 * c + 1]; y2 += sA[3 * c + 2]; });
         *reinterpret_cast<float4 *>(a.GY2 + (long)r * 4) = make_float4(y0, y1, y2, l == l0 ? cd : a.b.dinv[r]);
     }
+    HMARK(8);
+#ifdef GMC_STAMP
+    __builtin_amdgcn_s_waitcnt(0);  // every store of this wave acknowledged
+    HMARK(9);
+#endif
 }
 
 // GY2 for a caller-supplied dLoss/dP (autograd path): same phases 2b/3 as above.

@@ -141,10 +141,7 @@ __global__ __launch_bounds__(256) void hidden_bwd_slab_kernel(HiddenSlabArgs a) 
     }
     // fold lanes with equal q inside the wave (xor over the lane bits above log2 Q), then waves
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int o = 32; o >= Q; o >>= 1) acc[i] += __shfl_xor(acc[i], o, GMC_WAVE);
-    }
+    for (int i = 0; i < 16; ++i) acc[i] = gmc::xor_tree<32, Q>(acc[i]);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane < Q) {
 #pragma unroll

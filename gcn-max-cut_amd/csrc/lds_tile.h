@@ -13,6 +13,11 @@
 // contains none of this.
 #ifdef GMC_STAMP
 static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per translation unit (no device linking)
+#ifdef GMC_MARKS_ONLY  // wall-clock marks without the per-phase cycle counters (which cost a few % themselves)
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#else
 #define STAMP_DECL unsigned long long st_last = __builtin_amdgcn_s_memtime(); unsigned long long st_acc[12] = {}
 #define STAMP(i)                                                     \
     do {                                                             \
@@ -27,6 +32,7 @@ static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per trans
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && threadIdx.x < 1024)         \
             for (int i = 0; i < 12; ++i) g_stamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + i] = st_acc[i]; \
     } while (0)
+#endif
 // wall-clock marks (s_memrealtime: one 100 MHz counter for the whole chip) in slots 12..15 of the workgroup:
 // kernel entry, tile loop start, tile loop end, kernel exit - where a launch's fixed time goes
 #define MARK(i)                                                                                  \

@@ -172,10 +172,7 @@ __global__ GMC_LDS_BOUNDS void spmm_lds_kernel(TileArgs a) {
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
             float z0 = zr[k][0], z1 = zr[k][1], z2 = zr[k][2];
-#pragma unroll
-            for (int o = Q / 2; o > 0; o >>= 1) {
-                z0 += __shfl_xor(z0, o, GMC_WAVE); z1 += __shfl_xor(z1, o, GMC_WAVE); z2 += __shfl_xor(z2, o, GMC_WAVE);
-            }
+            z0 = gmc::xor_tree<Q / 2, 1>(z0); z1 = gmc::xor_tree<Q / 2, 1>(z1); z2 = gmc::xor_tree<Q / 2, 1>(z2);
             const int l = lrow + k * kRowsPerPass;
             if (q == 0 && l < n) {
                 zp[3 * l] = z0 * sc[k]; zp[3 * l + 1] = z1 * sc[k]; zp[3 * l + 2] = z2 * sc[k];
