@@ -213,6 +213,8 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     // overflow lists (OVF): per-row descriptors and the graph's first blocks in the spare LDS (single copy: the OVF
     // flavour pays a third barrier per graph to rewrite it between gather #2 of one graph and gather #1 of the next)
     OvfLds ol{};
+    constexpr int kOvfRows = (ACC * kRowsPerPass + kThreads - 1) / kThreads;
+    OvfReq<kOvfRows> orq;
     if constexpr (ovf) ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
     // rows past n get eight pad ids (the zero row n): their gathers return +0, so the tile loop needs
     // no exec masks - such a thread adds 0 to its dW1 accumulator and writes 0 into the zero row
@@ -258,7 +260,8 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     auto wait_piece = [&](int k, int pieces) {
         const int younger = pieces - 1 - k;   // wave-uniform
 #if defined(GMC_BWD1_FULLWAIT) || !defined(GMC_BWD1_LEAD)   // default: the whole tile before the first transform
-        dma_wait();
+        // (the ACC id loads of graph g+1 issued behind gather #2 are younger than the tile and stay in flight)
+        if (k == 0) vm_wait<ACC>();
         return;
 #endif
         if (younger <= 0) dma_wait();
@@ -284,7 +287,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         hlast = make_float4(v.x, v.y, v.z, v.w);
     }
     load_ids(r0, n);
-    if constexpr (ovf) ovf_setup(a.b, r0, n, ol);
+    if constexpr (ovf) ovf_setup<kOvfRows>(a.b, r0, n, ol);
     zero_pads(bufA, n);
     dma_wait();
     __syncthreads();
@@ -330,6 +333,22 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         // so that every path issues the same number of loads: a branch here makes the compiler wait for vmcnt(0)
         // at the join, i.e. for these very loads, before the first gather read)
         if (KREG > 0) load_hreg(nn > 0 ? r0n : r0, nn > 0 ? nn : n);
+        // OVF: my rows' overflow descriptors, read ONCE per graph - barrier A has published them - and ahead of gather
+        // #1: the two fix-up loops find a wave's hub rows by ballot (no LDS round trip in front of a branch), and a
+        // wave without hub rows skips them on a scalar branch
+        unsigned hd[ovf ? ACC : 1] = {};   // my rows' descriptors (0: no overflow blocks / row past n)
+        bool hub_any = false;              // wave-uniform
+        if constexpr (ovf) {
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) hd[k] = ovf_desc(ol, min(lrow + k * kRowsPerPass, n - 1));
+            unsigned any = 0;
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                if (lrow + k * kRowsPerPass >= n) hd[k] = 0;
+                any |= hd[k];
+            }
+            hub_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+        }
         // (2) U tile = dinv o (A @ Gs)
         zero_pads(bufB, n);
         float dv[ACC];
@@ -339,20 +358,21 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
         for (int k = 0; k < ACC; ++k) {
             const int l = min(lrow + k * kRowsPerPass, n);  // rows past n: 0 into the zero row
             float4 u;
-            if constexpr (ovf) u = gather_ids8_halves<FS>(bufA, idr[k], q);   // (see lds_tile.h)
+            if constexpr (GMC_OVF_HALVES_BWD && ovf) u = gather_ids8_halves<FS>(bufA, idr[k], q);   // (see lds_tile.h)
             else u = ABL(5) ? make_float4(dv[k], dv[k], dv[k], dv[k]) : gather_ids8<FS, false, NS>(bufA, idr[k], nullptr, q);
             u.x *= dv[k]; u.y *= dv[k]; u.z *= dv[k]; u.w *= dv[k];
             reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
         }
-        if constexpr (ovf) {   // hub rows: their overflow blocks, added to the U row this thread has just written
+        if (hub_any) {   // hub rows: their overflow blocks, added to the U row its lanes have just written
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n && ovf_desc(ol, l) != 0) {
-                    const float4 t = gather_overflow<FS>(bufA, ol, l, q);
-                    float4 *cell = reinterpret_cast<float4 *>(bufB) + l * Q + q;
+                const int lm = lrow + k * kRowsPerPass;
+                float4 mine = gmc::f4_zero();
+                for_hub_rows<FS, 0>(hd[k], lm, q, bufA, nullptr, ol, n, [&](int l, const float4 t) { if (lm == l) mine = t; });
+                if (hd[k] != 0) {   // (the read-modify-writes of all my wave's hub rows at once, outside the serial loop)
+                    float4 *cell = reinterpret_cast<float4 *>(bufB) + lm * Q + q;
                     const float4 c = *cell;
-                    *cell = make_float4(fmaf(t.x, dv[k], c.x), fmaf(t.y, dv[k], c.y), fmaf(t.z, dv[k], c.z), fmaf(t.w, dv[k], c.w));
+                    *cell = make_float4(fmaf(mine.x, dv[k], c.x), fmaf(mine.y, dv[k], c.y), fmaf(mine.z, dv[k], c.z), fmaf(mine.w, dv[k], c.w));
                 }
             }
         }
@@ -371,6 +391,10 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
             zero_pads(bufA, nn);
 #pragma unroll
             for (int k = KREG; k < ACC; ++k) pieces += wrow0 + k * kRowsPerPass < nn ? 1 : 0;
+            // OVF: the next graph's block offsets travel with its tile; its blocks are requested behind the transforms
+            // (the first point where the offsets are known to have landed) and fly through the fix-up loop and the
+            // barrier in front of the commit: no memory round trip of the overflow lists is left in the open
+            if constexpr (ovf) ovf_request(a.b, r0n, nn, (int)threadIdx.x, orq);
         }
         STAMP(5);  // fetch issue
         const float *wbase = HAS_VAL ? a.b.ell_vals + (long)r0 * W : nullptr;
@@ -396,7 +420,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 }
                 const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
                 if constexpr (HAS_VAL) acc[k] += gmc::f4v(gather_ids8<FS, true, NS>(bufB, idr[k], wbase + (long)l * W, q));
-                else if constexpr (ovf) acc[k] += gmc::f4v(gather_ids8_halves<FS>(bufB, idr[k], q));
+                else if constexpr (GMC_OVF_HALVES_BWD && ovf) acc[k] += gmc::f4v(gather_ids8_halves<FS>(bufB, idr[k], q));
                 else acc[k] += ABL(4) ? (gmc::v4f)(__uint_as_float(idr[k].x)) : gather_ids8_pk<FS, NS>(bufB, idr[k], q);
                 // the sum is needed HERE (its only user is the store after the graph loop: left alone the
                 // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
@@ -412,21 +436,26 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 transform(j, nn, gyn);
             }
         }
-        if constexpr (ovf) {   // hub rows: their overflow blocks into the dW1 accumulators
+        if constexpr (ovf) {
+            if (nn > 0 && !ABL(1)) ovf_blocks(a.b, (int)threadIdx.x, ol, orq);
+        }
+        if (hub_any) {   // hub rows: their overflow blocks into the dW1 accumulators
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n && ovf_desc(ol, l) != 0) acc[k] += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
+                const int lm = lrow + k * kRowsPerPass;
+                for_hub_rows<FS, 0>(hd[k], lm, q, bufB, nullptr, ol, n, [&](int l, const float4 t) { if (lm == l) acc[k] += gmc::f4v(t); });
             }
         }
         STAMP(6);  // gather 2 + transform of the next graph
-        if (!kRecycle) dma_wait();
+        // (default order: the wait in front of the first transform covered the tile; the id loads of graph g+1 - and an
+        // OVF kernel's block loads - stay in flight through the barrier below)
+        if (!kRecycle && kLead != ACC) dma_wait();
         STAMP(7);
         if (kLead != ACC && nn > 0) load_ids(r0n, nn);   // (interleaved tuning builds: the ids are in use until here)
         if constexpr (ovf) {
             if (nn > 0) {   // every wave is done with this graph's descriptors / blocks before they are rewritten
                 loop_barrier();
-                ovf_setup(a.b, r0n, nn, ol);   // (published by barrier A)
+                ovf_commit(a.b, nn, (int)threadIdx.x, ol, orq);   // (published by barrier A; no memory access of its own)
             }
         }
         STAMP(9);
@@ -484,6 +513,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
     float4 rc[RC];
     // overflow lists (OVF): per-row descriptors and the graph's first blocks (spare LDS) are set up with the table
     OvfLds ol{};
+    OvfReq<RC> orq;
     if constexpr (ovf) ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
 #pragma unroll
     for (int k = 0; k < ACC; ++k) acc[k] = (gmc::v4f)(0.f);
@@ -503,9 +533,10 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             const int i = threadIdx.x + k * kThreads;
             rc[k] = reinterpret_cast<const float4 *>(a.GY2)[r0 + min(i, n - 1)];
         }
+        if constexpr (ovf) ovf_request(a.b, r0, n, (int)threadIdx.x, orq);   // the graph's block offsets travel with the table
     };
+    // (OVF: the blocks themselves are requested by the caller once the offsets have landed - ovf_blocks - and written here)
     auto commit = [&](int r0, int n) {  // table, row constants (and the zero rows the padding entries point at)
-        if constexpr (ovf) ovf_setup(a.b, r0, n, ol);   // (between two barriers: nobody reads the previous graph's any more)
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int i = threadIdx.x + k * kThreads;
@@ -520,10 +551,12 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
             bufA[n * FS + threadIdx.x] = 0.f;
             bufB[n * FS + threadIdx.x] = 0.f;
         }
+        if constexpr (ovf) ovf_commit(a.b, n, (int)threadIdx.x, ol, orq);   // (between two barriers: nobody reads the previous graph's any more)
     };
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     fetch(r0, n);
+    if constexpr (ovf) ovf_blocks(a.b, (int)threadIdx.x, ol, orq);
     commit(r0, n);
     dma_wait();
     __syncthreads();
@@ -531,6 +564,20 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
         const int r0n = r0 + n;                                        // == goff[g + 1]
         const int nn = g + 1 < g1 ? sload(a.b.goff, g + 2) - r0n : n;  // next graph's size (used after gather 1; scalar cache: see sload)
         float dv[ACC];
+        // OVF: my rows' overflow descriptors, read once per graph: the fix-up loops find a wave's hub rows by ballot,
+        // and a wave without hub rows skips them on a scalar branch
+        // (this kernel has no registers to keep them in: one bit per row lives across the graph, a fix-up loop reads
+        // the descriptor of its pass's row again - one LDS read, all hub rows of the wave at once)
+        unsigned hub = 0;
+        bool hub_any = false;              // wave-uniform
+        if constexpr (ovf) {
+            unsigned d[ACC];
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) d[k] = ovf_desc(ol, min(lrow + k * kRowsPerPass, n - 1));
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) hub |= (d[k] != 0 && lrow + k * kRowsPerPass < n ? 1u : 0u) << k;
+            hub_any = __builtin_amdgcn_ballot_w64(hub != 0) != 0;
+        }
         // (1) H -> Gs in place + column partials (row constants: staged in bufB with the table)
 #pragma unroll
         for (int k = 0; k < ACC; ++k) {
@@ -550,15 +597,17 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
                 reinterpret_cast<float4 *>(bufB)[l * Q + q] = u;
             }
         }
-        if constexpr (ovf) {   // hub rows: their overflow blocks, added to the U row this thread has just written
+        if (hub_any) {   // hub rows: their overflow blocks, added to the U row its lanes have just written
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n && ovf_desc(ol, l) != 0) {
-                    const float4 t = gather_overflow<FS>(bufA, ol, l, q);
-                    float4 *cell = reinterpret_cast<float4 *>(bufB) + l * Q + q;
+                const int lm = lrow + k * kRowsPerPass;
+                const unsigned hdk = (hub >> k & 1u) ? ovf_desc(ol, lm) : 0u;
+                float4 mine = gmc::f4_zero();
+                for_hub_rows<FS, 0>(hdk, lm, q, bufA, nullptr, ol, n, [&](int l, const float4 t) { if (lm == l) mine = t; });
+                if (hdk != 0) {   // (the read-modify-writes of all my wave's hub rows at once, outside the serial loop)
+                    float4 *cell = reinterpret_cast<float4 *>(bufB) + lm * Q + q;
                     const float4 c = *cell;
-                    *cell = make_float4(fmaf(t.x, dv[k], c.x), fmaf(t.y, dv[k], c.y), fmaf(t.z, dv[k], c.z), fmaf(t.w, dv[k], c.w));
+                    *cell = make_float4(fmaf(mine.x, dv[k], c.x), fmaf(mine.y, dv[k], c.y), fmaf(mine.z, dv[k], c.z), fmaf(mine.w, dv[k], c.w));
                 }
             }
         }
@@ -574,14 +623,18 @@ __global__ GMC_LDS_BOUNDS void bwd1_lds_kernel(Bwd1Args a) {
                 asm volatile("" : "+v"(acc[k]));
             }
         }
-        if constexpr (ovf) {   // hub rows: their overflow blocks into the dW1 accumulators
+        if (hub_any) {   // hub rows: their overflow blocks into the dW1 accumulators
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
-                const int l = lrow + k * kRowsPerPass;
-                if (l < n && ovf_desc(ol, l) != 0) acc[k] += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
+                const int lm = lrow + k * kRowsPerPass;
+                const unsigned hdk = (hub >> k & 1u) ? ovf_desc(ol, lm) : 0u;
+                for_hub_rows<FS, 0>(hdk, lm, q, bufB, nullptr, ol, n, [&](int l, const float4 t) { if (lm == l) acc[k] += gmc::f4v(t); });
             }
         }
         dma_wait();
+        if constexpr (ovf) {
+            if (g + 1 < g1) ovf_blocks(a.b, (int)threadIdx.x, ol, orq);   // (the offsets have landed with the tile; the blocks fly through the barrier)
+        }
         __syncthreads();  // everyone is done with graph g's table and U tile; DMA has landed
         if (g + 1 < g1) commit(r0n, nn);
         __syncthreads();

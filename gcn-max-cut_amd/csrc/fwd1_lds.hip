@@ -94,35 +94,66 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
         if (it != it0) lds_barrier();  // every wave is done with the previous graph's table and tiles
         // graph prologue: every global read is issued before the first use (one memory latency)
         dma(s_lo);
-        // overflow lists of this graph: per-row descriptors and the first blocks into the spare LDS (published by
-        // barrier 1 of the first slice; the previous graph's readers are behind the barrier above)
+        // overflow lists of this graph: per-row descriptors and the blocks into the spare LDS (published by barrier 1
+        // of the first slice; the previous graph's readers are behind the barrier above).  Requested here, committed
+        // below behind the prologue's other reads: one round trip for all of them, one more for the blocks.
+        // (OVF: the prologue's per-thread addresses are computed from a laundered thread id - as loop invariants of the
+        // graph loop they were spilled, and each of the eight reloads per graph came with its own s_waitcnt vmcnt(0).)
+        int tid = threadIdx.x;
+        if constexpr (ovf) asm volatile("" : "+v"(tid));
         OvfLds ol{};
+        constexpr int kOvfRows = (ACC * kRowsPerPass + kThreads - 1) / kThreads;
+        OvfReq<kOvfRows> orq;
         if constexpr (ovf) {
             ol = ovf_lds(lds, a.own_lds, a.b.n_max, a.ovf_cap);
-            ovf_setup(a.b, r0, n, ol);
+            ovf_request(a.b, r0, n, tid, orq);
         }
         float4 cn = gmc::f4_zero();   // CSL: constants of my column of the NEXT slice (threads < FS), in flight
         if (CSL && threadIdx.x < FS) cn = col_consts(s_lo * FS + (int)threadIdx.x);
         float sc[ACC];
 #pragma unroll
         for (int k = 0; k < ACC; ++k) sc[k] = a.scale[r0 + min(lrow + k * kRowsPerPass, n - 1)];
+        // OVF: the overflow descriptors of my rows (16 bits each: blocks << 12 | first block; 0 = none), from the block
+        // offsets themselves, once per graph and kept in registers - the slice loop never reads a descriptor from LDS
+        // in front of a branch (under a workgroup's gathers every dependent LDS hop is ~500 cycles of queueing), and a
+        // wave none of whose rows is a hub row skips the fix-up loops on a scalar branch
+        unsigned hub[(ACC + 1) / 2] = {};   // two 16-bit descriptors per register
+        auto desc_of = [&](int k) { return (hub[k / 2] >> (16 * (k & 1))) & 0xffffu; };
+        int hp0[ovf ? ACC : 1], hp1[ovf ? ACC : 1];
+        if constexpr (ovf) {
+#pragma unroll
+            for (int k = 0; k < ACC; ++k) {
+                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                hp0[k] = a.b.ovf_ptr[r0 + l]; hp1[k] = a.b.ovf_ptr[r0 + l + 1];
+            }
+        }
         uint4 pt[NT];
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.b.ell + (long)r0 * W);
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
-                const int i = threadIdx.x + k * kThreads;
+                const int i = tid + k * kThreads;
                 pt[k] = i < n * (W / 8) ? src[i] : make_uint4(0, 0, 0, 0);
+            }
+            if constexpr (ovf) {
+                ovf_blocks(a.b, tid, ol, orq);
+                ovf_commit(a.b, n, tid, ol, orq);
+                const int ob = orq.ob;   // (wave-uniform after ovf_blocks)
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) {
+                    const unsigned dsc = hp1[k] > hp0[k] ? (unsigned)(((hp1[k] - hp0[k]) << 12) | (hp0[k] - ob)) : 0u;
+                    hub[k / 2] |= dsc << (16 * (k & 1));
+                }
             }
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
-                const int i = threadIdx.x + k * kThreads;
+                const int i = tid + k * kThreads;
                 if (i < n * (W / 8)) reinterpret_cast<uint4 *>(nb)[i] = pt[k];
             }
         }
-        if (threadIdx.x < kPadRows * FS) {  // the zero rows padding entries point at
-            bufA[(long)n * FS + threadIdx.x] = 0.f;
-            bufB[(long)n * FS + threadIdx.x] = 0.f;
+        if (tid < kPadRows * FS) {  // the zero rows padding entries point at
+            bufA[(long)n * FS + tid] = 0.f;
+            bufB[(long)n * FS + tid] = 0.f;
         }
         gmc::v2f z01[ACC];  // (Z[r,0], Z[r,1]) partial of my 4 columns, per row
         float z2[ACC];      //  Z[r,2]
@@ -174,7 +205,7 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     // rows past n redo row n-1 (same value to the same address): no exec-mask juggling
                     const int lc = min(l, n - 1);
                     float4 t;
-                    if constexpr (ovf && !HAS_VAL) t = gather_ids8_halves<FS>(bufA, cur, q);   // (see lds_tile.h)
+                    if constexpr (GMC_OVF_HALVES_FWD && ovf && !HAS_VAL) t = gather_ids8_halves<FS>(bufA, cur, q);   // (see lds_tile.h)
                     else t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
                                     : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
@@ -191,16 +222,26 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     }
                 }
             }
-            if constexpr (ovf) {   // hub rows: add their overflow blocks to the T0 row this thread has just written
+            bool hub_any = false;   // wave-uniform
+            if constexpr (ovf) {
+                unsigned any = 0;
+#pragma unroll
+                for (int i = 0; i < (ACC + 1) / 2; ++i) any |= hub[i];
+                hub_any = __builtin_amdgcn_ballot_w64(any != 0) != 0;
+            }
+            if (hub_any) {   // hub rows: add their overflow blocks to the T0 row its lanes have just written
+                unsigned dk[ACC];   // my rows' descriptors (rows past n: the thread that OWNS row n-1 adds - a read-modify-write is not idempotent)
+#pragma unroll
+                for (int k = 0; k < ACC; ++k) dk[k] = lrow + k * kRowsPerPass < n ? desc_of(k) : 0u;
 #pragma unroll
                 for (int k = 0; k < ACC; ++k) {
-                    const int lc = min(lrow + k * kRowsPerPass, n - 1);
-                    // (rows past n: the thread that OWNS row n-1 adds - a read-modify-write is not idempotent)
-                    if (lrow + k * kRowsPerPass < n && ovf_desc(ol, lc) != 0) {
-                        float4 t = gather_overflow<FS>(bufA, ol, lc, q);
-                        float4 *cell = reinterpret_cast<float4 *>(bufB) + lc * Q + q;
+                    const int lm = lrow + k * kRowsPerPass;
+                    float4 mine = gmc::f4_zero();
+                    for_hub_rows<FS, 0>(dk[k], lm, q, bufA, nullptr, ol, n, [&](int l, const float4 t) { if (lm == l) mine = t; });
+                    if (dk[k] != 0) {
+                        float4 *cell = reinterpret_cast<float4 *>(bufB) + lm * Q + q;
                         const float4 c = *cell;
-                        *cell = make_float4(fmaf(t.x, sc[k], c.x), fmaf(t.y, sc[k], c.y), fmaf(t.z, sc[k], c.z), fmaf(t.w, sc[k], c.w));
+                        *cell = make_float4(fmaf(mine.x, sc[k], c.x), fmaf(mine.y, sc[k], c.y), fmaf(mine.z, sc[k], c.z), fmaf(mine.w, sc[k], c.w));
                     }
                 }
             }
@@ -228,7 +269,11 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) scm[k] = col_pad ? 0.f : sc[k];
             auto emit = [&](int k, const gmc::v4f acc) {
-                const int l = min(lrow + k * kRowsPerPass, n - 1);
+                int l = min(lrow + k * kRowsPerPass, n - 1);
+                // OVF: the store address is computed here - as an invariant of the slice loop the row's 64-bit offset was
+                // spilled, and its reload in front of the store came with s_waitcnt vmcnt(0): a wait for the W1 tile just
+                // requested, in the middle of the gather that is supposed to hide it
+                if constexpr (ovf) asm volatile("" : "+v"(l));
                 const gmc::v2f s2 = gmc::splat2(scm[k]);
                 const gmc::v2f ylo = gmc::pk_fma((gmc::v2f){acc.x, acc.y}, s2, blo);
                 const gmc::v2f yhi = gmc::pk_fma((gmc::v2f){acc.z, acc.w}, s2, bhi);
@@ -246,15 +291,15 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
 #pragma unroll
             for (int k = 0; k < ACC; ++k) {
                 const int l = min(lrow + k * kRowsPerPass, n - 1);
-                // hub rows (OVF kernels, a 16-bit LDS word tells) are emitted by the fix-up loop below, with their
+                // hub rows (OVF kernels) are emitted by the fix-up loop below, with their
                 // overflow blocks: H is relu of the WHOLE sum.  Every thread still stores exactly ACC rows per slice.
                 bool later = false;
-                if constexpr (ovf) later = ovf_desc(ol, l) != 0;
+                if constexpr (ovf) later = desc_of(k) != 0;
                 if constexpr (W == 8) {
                     const uint4 cur = ids2;
                     if (k + 1 < ACC) ids2 = reinterpret_cast<const uint4 *>(nb)[min(l + kRowsPerPass, n - 1)];
                     gmc::v4f h;
-                    if constexpr (ovf) h = gmc::f4v(gather_ids8_halves<FS>(bufB, cur, q));
+                    if constexpr (GMC_OVF_HALVES_FWD && ovf) h = gmc::f4v(gather_ids8_halves<FS>(bufB, cur, q));
                     else h = ABL(4) ? (gmc::v4f)(__uint_as_float(cur.x)) : gather_ids8_pk<FS, NS>(bufB, cur, q);
                     if (!later) emit(k, h);
                 } else {
@@ -262,15 +307,13 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     if (!later) emit(k, h);
                 }
             }
-            if constexpr (ovf) {
+            if (hub_any) {   // hub rows: table slots and overflow blocks in one list, gathered by the whole wave
 #pragma unroll
                 for (int k = 0; k < ACC; ++k) {
-                    const int l = min(lrow + k * kRowsPerPass, n - 1);
-                    if (ovf_desc(ol, l) != 0) {
-                        gmc::v4f h = gmc::f4v(gather_row<FS, W, false, NS>(bufB, nb, nullptr, l, q));
-                        h += gmc::f4v(gather_overflow<FS>(bufB, ol, l, q));
-                        emit(k, h);
-                    }
+                    const int lm = min(lrow + k * kRowsPerPass, n - 1);
+                    gmc::v4f h = (gmc::v4f)(0.f);
+                    for_hub_rows<FS, W>(desc_of(k), lm, q, bufB, nb, ol, n, [&](int l, const float4 t) { if (lm == l) h = gmc::f4v(t); });
+                    if (desc_of(k) != 0) emit(k, h);
                 }
             }
             STAMP(6);  // gather 2

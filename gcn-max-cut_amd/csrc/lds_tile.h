@@ -59,6 +59,16 @@ static __device__ unsigned long long g_stamps[4096 * 16];  // one copy per trans
 #endif
 #define ABL(n) (GMC_ABLATE == (n))
 
+// OVF flavours of the 8-slot kernels: 1 = read a row's slots four at a time (gather_ids8_halves: fewer registers in
+// flight), 0 = the plain kernels' gathers (eight reads in flight per row).  The backward needs the former to stay
+// free of scratch; the forward does not any more (its hub rows are a register bit now, not LDS descriptors).
+#ifndef GMC_OVF_HALVES_FWD
+#define GMC_OVF_HALVES_FWD 0
+#endif
+#ifndef GMC_OVF_HALVES_BWD
+#define GMC_OVF_HALVES_BWD 1
+#endif
+
 namespace {
 
 // threads per workgroup of every kernel in this file; GMC_LDS_THREADS=512 builds the tuning variant
@@ -385,48 +395,133 @@ __device__ __forceinline__ OvfLds ovf_lds(const float *lds_base, int own_bytes, 
         (int)((unsigned)(size_t)(__attribute__((address_space(3))) const float *)lds_base + (unsigned)own_bytes));
     return OvfLds{base, base + (unsigned)ovf_desc_bytes(n_max), cap};
 }
-// set up desc[] and blocks[] for the graph at rows [r0, r0 + n); callers separate this from the gathers that read the
-// previous graph's with a barrier on either side
-__device__ __forceinline__ void ovf_setup(const gmc_batch &b, int r0, int n, const OvfLds &o) {
+// Set up desc[] and blocks[] for the graph at rows [r0, r0 + n) in two steps, so that a caller can put its own global
+// reads of the graph between them and pay ONE memory round trip for all of it (+ one for the blocks, whose place
+// depends on the first): ovf_request issues the loads (a thread's row(s) - a graph has at most 2 * kThreads rows - and
+// the graph's first / last block offset), ovf_commit writes the descriptors and copies the blocks.  Callers separate
+// the commit from the gathers that read the previous graph's LDS copy with a barrier on either side.  `tid` =
+// threadIdx.x, possibly laundered through an empty asm by the caller (keeps the address arithmetic inside its loop:
+// hoisted out as loop invariants, these values were spilled and every reload came with its own s_waitcnt vmcnt(0)).
+// Registers: ROWS = rows of a graph per thread (1 for the ACC = 4 flavours: n <= kThreads); one block per thread in
+// registers - graphs with more than kThreads blocks (the 16-bit descriptors allow 4095) copy the rest in a loop of
+// dependent round trips inside the commit.  Between step 2 and step 3 a thread holds its descriptors (16 bits each)
+// and its block: what a kernel carries across a gather is 4 registers (ROWS = 1), then 5.
+template <int ROWS>
+struct OvfReq {
+    int p0[ROWS], p1[ROWS], ob, oe;   // step 1
+    uint4 blk;                        // step 2
+};
+// step 1: the block offsets of my row(s) and of the graph's first / last row
+template <int ROWS>
+__device__ __forceinline__ void ovf_request(const gmc_batch &b, int r0, int n, int tid, OvfReq<ROWS> &q) {
+    q.ob = b.ovf_ptr[r0];
+    q.oe = b.ovf_ptr[r0 + n];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int i = min(tid + j * kThreads, n - 1);
+        q.p0[j] = b.ovf_ptr[r0 + i];
+        q.p1[j] = b.ovf_ptr[r0 + i + 1];
+    }
+}
+// step 2 (needs step 1's answer): my block of the graph's first kThreads.  Unconditional (a predicated load gets its
+// own wait at the join): indices past the graph's last block re-read that block, a graph without blocks reads block
+// 0 of the batch (an OVF launch has at least one).  The row offsets turn into descriptors here (p0[j] <- descriptor).
+template <int ROWS>
+__device__ __forceinline__ void ovf_blocks(const gmc_batch &b, int tid, const OvfLds &o, OvfReq<ROWS> &q) {
+    const int ob = __builtin_amdgcn_readfirstlane(q.ob);
+    const int nblk = min(__builtin_amdgcn_readfirstlane(q.oe) - ob, o.cap);
+    const uint4 *src = reinterpret_cast<const uint4 *>(b.ovf_ids) + (nblk > 0 ? ob : 0);
+    q.blk = src[min(tid, max(nblk - 1, 0))];
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) q.p0[j] = q.p1[j] > q.p0[j] ? ((q.p1[j] - q.p0[j]) << 12) | (q.p0[j] - ob) : 0;
+    q.ob = ob; q.oe = nblk;   // (wave-uniform from here on)
+}
+// step 3: descriptors and blocks into LDS
+template <int ROWS>
+__device__ __forceinline__ void ovf_commit(const gmc_batch &b, int n, int tid, const OvfLds &o, const OvfReq<ROWS> &q) {
     using lds_u16 = __attribute__((address_space(3))) unsigned short;
     typedef unsigned u4 __attribute__((ext_vector_type(4)));
     using lds_u4 = __attribute__((address_space(3))) u4;
-    const int ob = b.ovf_ptr[r0], nblk = b.ovf_ptr[r0 + n] - ob;
-    for (int i = threadIdx.x; i < n; i += kThreads) {
-        const int p0 = b.ovf_ptr[r0 + i], p1 = b.ovf_ptr[r0 + i + 1];
-        *(lds_u16 *)(size_t)(o.desc + 2u * (unsigned)i) = (unsigned short)(p1 > p0 ? ((p1 - p0) << 12) | (p0 - ob) : 0);
+    const int ob = __builtin_amdgcn_readfirstlane(q.ob), nblk = __builtin_amdgcn_readfirstlane(q.oe);
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        const int i = tid + j * kThreads;
+        if (i < n) *(lds_u16 *)(size_t)(o.desc + 2u * (unsigned)i) = (unsigned short)q.p0[j];
     }
-    const uint4 *src = reinterpret_cast<const uint4 *>(b.ovf_ids) + ob;
-    for (int i = threadIdx.x; i < min(nblk, o.cap); i += kThreads) {
-        const uint4 v = src[i];
-        *(lds_u4 *)(size_t)(o.blocks + 16u * (unsigned)i) = (u4){v.x, v.y, v.z, v.w};
+    if (tid < nblk) *(lds_u4 *)(size_t)(o.blocks + 16u * (unsigned)tid) = (u4){q.blk.x, q.blk.y, q.blk.z, q.blk.w};
+    if (nblk > kThreads) {   // (wave-uniform, rare: a graph with more than 1024 overflow blocks)
+        const uint4 *src = reinterpret_cast<const uint4 *>(b.ovf_ids) + ob;
+        for (int i = tid + kThreads; i < nblk; i += kThreads) {
+            const uint4 v = src[i];
+            *(lds_u4 *)(size_t)(o.blocks + 16u * (unsigned)i) = (u4){v.x, v.y, v.z, v.w};
+        }
     }
+}
+template <int ROWS>
+__device__ __forceinline__ void ovf_setup(const gmc_batch &b, int r0, int n, const OvfLds &o) {
+    OvfReq<ROWS> q;
+    ovf_request(b, r0, n, (int)threadIdx.x, q);
+    ovf_blocks(b, (int)threadIdx.x, o, q);
+    ovf_commit(b, n, (int)threadIdx.x, o, q);
 }
 // a row's descriptor word (0: no overflow blocks)
 __device__ __forceinline__ unsigned ovf_desc(const OvfLds &o, int l) {
     using lds_u16 = __attribute__((address_space(3))) const unsigned short;
     return *(lds_u16 *)(size_t)(o.desc + 2u * (unsigned)l);
 }
-// overflow part of row l's sum (0 for the rows that have none: one 16-bit LDS read); one tile read at a time, LDS
-// only.  Callers keep this OUT of their gather loops (a fix-up loop over the thread's rows behind the main loop).
-template <int FS>
-__device__ __forceinline__ float4 gather_overflow(const float *tile, const OvfLds &o, int l, int q) {
+// ONE hub row's sum computed by the whole wave: lane (j, q) reads the tile row of the row's j-th, (j + 64/Q)-th, ...
+// neighbour for its four columns, a butterfly over j folds them (fixed order: bitwise reproducible); every lane returns
+// the sum for its q.  The neighbour list = the row's WT table slots (WT = 0: none - the caller has that part already)
+// followed by its overflow blocks (descriptor d, wave-uniform); entries past the end read `zero_row`, a tile row of
+// zeros, as the padding ids do.  The ids of round r+1 are requested ahead of the tile reads of round r: under a
+// workgroup's gathers every dependent LDS hop costs ~500 cycles of queueing, so a row costs (1 + rounds) hops.
+// (Round 3, first version: the row's own four lanes walked the list, two tile reads per step of a dependent chain -
+// 2,400 cycles per gather for a degree-40 row with everybody else at the barrier: the workgroup that met the ONE
+// hub row of a 160-graph batch took 150 us, the others 110.)
+template <int FS, int WT>
+__device__ __forceinline__ float4 gather_hub_row_wave(const float *tile, const unsigned short *nb, const OvfLds &o, int l, unsigned d, int q,
+                                                      int zero_row) {
+    constexpr int Q = FS / 4, J = 64 / Q;
     typedef float v4f __attribute__((ext_vector_type(4)));
     using lds_f4 = __attribute__((address_space(3))) const v4f;
-    using lds_u32 = __attribute__((address_space(3))) const unsigned;
-    float4 acc = gmc::f4_zero();
-    const unsigned d = ovf_desc(o, l);
-    if (d == 0) return acc;
+    using lds_u16 = __attribute__((address_space(3))) const unsigned short;
+    const unsigned j = (threadIdx.x & 63u) / Q;
+    const unsigned ne = (unsigned)WT + 8u * (d >> 12);      // list entries (the last block's padding ids = zero row)
+    const unsigned ids = o.blocks + 16u * (d & 0xfffu);
+    const unsigned tab = WT > 0 ? (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short *)nb + 2u * (unsigned)(l * WT) : 0u;
     const unsigned tile_q = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
+    auto id_of = [&](unsigned e) {
+        const unsigned ec = min(e, ne - 1u);
+        const unsigned addr = ec < (unsigned)WT ? tab + 2u * ec : ids + 2u * (ec - (unsigned)WT);
+        return (unsigned)*(lds_u16 *)(size_t)addr;
+    };
+    v4f acc = (v4f)(0.f);
+    unsigned id = id_of(j);
 #pragma unroll 1
-    for (unsigned i = 4u * (d & 0xfffu), e = i + 4u * (d >> 12); i < e; ++i) {   // i = 4 * block + pair of ids
-        const unsigned pk = *(lds_u32 *)(size_t)(o.blocks + 4u * i);
-        const v4f x0 = *(lds_f4 *)(size_t)(tile_q + (pk & 0xffffu) * (unsigned)(FS * 4));
-        acc.x += x0.x; acc.y += x0.y; acc.z += x0.z; acc.w += x0.w;
-        const v4f x1 = *(lds_f4 *)(size_t)(tile_q + (pk >> 16) * (unsigned)(FS * 4));
-        acc.x += x1.x; acc.y += x1.y; acc.z += x1.z; acc.w += x1.w;
+    for (unsigned e0 = 0; e0 < ne; e0 += J) {               // (wave-uniform trip count)
+        const unsigned cur = e0 + j < ne ? id : (unsigned)zero_row;
+        if (e0 + J < ne) id = id_of(e0 + J + j);            // next round's ids travel with this round's tile reads
+        acc += *(lds_f4 *)(size_t)(tile_q + cur * (unsigned)(FS * 4));
     }
-    return acc;
+    return make_float4(gmc::xor_tree<32, Q>(acc.x), gmc::xor_tree<32, Q>(acc.y), gmc::xor_tree<32, Q>(acc.z), gmc::xor_tree<32, Q>(acc.w));
+}
+// For every DISTINCT hub row among this wave's rows of one pass (d_mine: my row's descriptor, 0 = no overflow blocks -
+// read by the caller for all its rows at once; l_mine: my row): f(l, t) with the row l (wave-uniform) and its overflow
+// sum t (for my q; WT > 0: the row's table slots included) - callers pick it up where l == l_mine and do everything
+// else (read-modify-writes, stores) OUTSIDE, for all their hub rows in parallel: the loop is a serial chain per hub row, and with 2-3 %
+// hub rows (G(n,p) tails) the fullest wave of a workgroup walks it five times while fifteen others wait at the barrier.
+// Runs on scalar branches: a wave without hub rows in the pass falls through.
+template <int FS, int WT, typename F>
+__device__ __forceinline__ void for_hub_rows(unsigned d_mine, int l_mine, int q, const float *tile, const unsigned short *nb, const OvfLds &o,
+                                             int zero_row, F &&f) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(d_mine != 0);
+    while (m) {
+        const int src = __builtin_ctzll(m);
+        const int l = __builtin_amdgcn_readlane(l_mine, src);
+        const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)d_mine, src);
+        m &= ~__builtin_amdgcn_ballot_w64(l_mine == l);     // every lane of the row (and its clamped duplicates) at once
+        f(l, gather_hub_row_wave<FS, WT>(tile, nb, o, l, d, q, zero_row));
+    }
 }
 
 // the kernels' NS specialisation for a table of W slots of which `slots` can hold a neighbour (gmc_batch.ell_slots)

@@ -4,7 +4,24 @@ import ctypes as C, numpy as np, torch, networkx as nx
 import gcn_max_cut_amd as pkg
 from gcn_max_cut_amd.Training import TrainingNeural as T
 B, n, d, F = 160, 1000, 7, 500
-hs = [pkg.from_networkx(nx.random_regular_graph(d, n, seed=3000 + i)) for i in range(B)]
+# MODE=d8: 8-regular graphs; MODE=hub: d = 7 with ONE degree-40 hub in the last graph (the OVF flavours of the kernels)
+MODE = os.environ.get("MODE", "d7")
+def graph(i):
+    if MODE == "gnp":   # G(n, p = 10/n) as bench.py's other_workloads
+        import bench
+        return bench.gnp_graph(n, 0.01, 200 + i)
+    if MODE == "gnp16":  # the same graphs with every degree capped at 16 (timing only)
+        import bench
+        g = bench.gnp_graph(n, 0.01, 200 + i).copy()
+        for v in list(g.nodes()):
+            while g.degree(v) > 16:
+                g.remove_edge(v, max(g.neighbors(v), key=g.degree))
+        return g
+    g = nx.random_regular_graph(8 if MODE == "d8" else d, n, seed=3000 + i)
+    if MODE == "hub" and i == B - 1:
+        for v in range(10, 10 + 33): g.add_edge(5, v)
+    return g
+hs = [pkg.from_networkx(graph(i)) for i in range(B)]
 batch = pkg.GraphBatch(hs, None)
 net, _, _ = T.setup_model_and_optimizer(T.TrainingConfig(n_nodes=1000, hidden_dim=F))
 eng = net.engine(); lib = pkg.hip.load()
@@ -32,11 +49,14 @@ eng.forward(batch); torch.cuda.synchronize()
 a = read(256, 'fwd')
 tot = a[:, :12].sum(1).mean()
 all_waves("fwd1", names["fwd"])
+print("fwd1 cycles per WG by phase (wave 0):", {k: int(a[:, i].mean()) for i, k in enumerate(names["fwd"])}, "epilogue", int(a[:, 7].mean()), "prologue", int(a[:, 11].mean()))
+print("fwd1 cycles per WG by phase (mean over waves):", {k: int(read.waves[:, :, i].mean()) for i, k in enumerate(names["fwd"])}, "prologue", int(read.waves[:, :, 11].mean()))
 print("fwd1 cycles per WG %.0f" % tot, {k: round(100 * a[:, i].mean() / tot, 1) for i, k in enumerate(names["fwd"])}, "epilogue %.1f prologue %.1f" % (100 * a[:, 7].mean() / tot, 100 * a[:, 11].mean() / tot))
 eng.train_fwd_bwd(batch); torch.cuda.synchronize()
 b = read(256, 'bwd')
 tot = b[:, :11].sum(1).mean()
 all_waves("bwd1", names["bwd"])
+print("bwd1 cycles per WG by phase (mean over waves):", {k: int(read.waves[:, :, i].mean()) for i, k in enumerate(names["bwd"])})
 print("bwd1 cycles per WG %.0f" % tot, {k: round(100 * b[:, i].mean() / tot, 1) for i, k in enumerate(names["bwd"])})
 
 def marks(x, label):
