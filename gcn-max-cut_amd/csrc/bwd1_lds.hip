@@ -247,14 +247,17 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     // H -> Gs for my cell of pass k of a graph of n rows (row constants from `gyl`).  Rows past n: constants 0 make
     // Gs = 0 and add 0 to the partials whatever (finite) bytes the cell holds - no exec mask, and no dependence on
     // when another wave zeroed the padding rows.
-    auto transform = [&](int k, int n, const float *gyl) {
+    auto row_consts = [&](int k, int n, const float *gyl) {
+        return reinterpret_cast<const float4 *>(gyl)[min(lrow + k * kRowsPerPass, n - 1)];
+    };
+    auto transform_with = [&](int k, int n, float4 rck) {
         if (ABL(7)) return;
         const int l = lrow + k * kRowsPerPass;
-        float4 rck = reinterpret_cast<const float4 *>(gyl)[min(l, n - 1)];
         if (l >= n) rck = gmc::f4_zero();
         const bool from_reg = kRecycle || k < KREG;
         transform_row(cs, reinterpret_cast<float4 *>(bufA) + min(l, n) * Q + q, rck, from_reg ? &hreg[KREG > 0 ? k % KREG : 0] : nullptr);
     };
+    auto transform = [&](int k, int n, const float *gyl) { transform_with(k, n, row_consts(k, n, gyl)); };
     // wait until piece k of the tile DMA this wave issued `pieces` pieces of has landed (they retire in issue order;
     // younger loads of the gather only make the wait longer than needed, never shorter)
     auto wait_piece = [&](int k, int pieces) {
@@ -411,11 +414,25 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
 #else
         constexpr int kLead = GMC_BWD1_LEAD < ACC ? GMC_BWD1_LEAD : ACC;   // tuning builds
 #endif
+        // GMC_BWD1_RCK_AHEAD (tuning): the row constants of transform k+1 are read from LDS together with the reads of
+        // gather row k instead of in a round trip of their own in front of the transform
+#ifndef GMC_BWD1_RCK_AHEAD
+#define GMC_BWD1_RCK_AHEAD 0
+#endif
+        constexpr bool kRckAhead = GMC_BWD1_RCK_AHEAD && kRecycle;
+        float4 rck_cur = gmc::f4_zero();
+        if (kRckAhead && nn > 0) rck_cur = row_consts(0, nn, gyn);
 #pragma unroll
         for (int k = 0; k < ACC + kLead; ++k) {
             if (k < ACC) {
+                float4 rck_next = gmc::f4_zero();
                 if (kRecycle && nn > 0) {   // cell k is in registers: turn it into Gs AHEAD of row k of the gather, then
-                    transform(k, nn, gyn);  // send for the cell that recycles its registers (longest possible shadow)
+                    if (kRckAhead) {        // send for the cell that recycles its registers (longest possible shadow)
+                        transform_with(k, nn, rck_cur);
+                        if (k + 1 < ACC) rck_next = row_consts(k + 1, nn, gyn);
+                    } else {
+                        transform(k, nn, gyn);
+                    }
                     if (k + KREG < ACC) load_cell(k % KREG, k + KREG, r0n, nn);
                 }
                 const int l = min(lrow + k * kRowsPerPass, n - 1);  // (weights of a real row; the ids are pads past n)
@@ -425,6 +442,10 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
                 // the sum is needed HERE (its only user is the store after the graph loop: left alone the
                 // optimiser sinks the adds and keeps four rows of reads, 128 VGPRs, alive)
                 asm volatile("" : "+v"(acc[k]));
+                if (kRckAhead) {
+                    asm volatile("" : "+v"(rck_next.x), "+v"(rck_next.y), "+v"(rck_next.z), "+v"(rck_next.w));
+                    rck_cur = rck_next;
+                }
                 // plain order (kLead == ACC): gather #2 is done with the ids - request graph g+1's now, so that they
                 // travel under the wait for the tile and the transforms instead of in front of barrier A
                 if (k == ACC - 1 && kLead == ACC && nn > 0) load_ids(r0n, nn);

@@ -209,7 +209,9 @@ __global__ GMC_LDS_BOUNDS void fwd1_lds_kernel(TileArgs a) {
                     else t = ABL(5) ? make_float4(sc[k], sc[k], sc[k], sc[k])
                                     : gather_ids8<FS, HAS_VAL, NS>(bufA, cur, HAS_VAL ? wbase + (long)lc * W : nullptr, q);
                     t.x *= sc[k]; t.y *= sc[k]; t.z *= sc[k]; t.w *= sc[k];
-                    reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
+                    // (OVF: a clamped duplicate must not write - its table-only sum could land on row n-1 AFTER the
+                    // owner's fix-up below has added that row's overflow blocks)
+                    if (!ovf || l < n) reinterpret_cast<float4 *>(bufB)[lc * Q + q] = t;
                 }
             } else {
 #pragma unroll

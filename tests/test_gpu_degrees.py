@@ -100,6 +100,42 @@ def test_one_hub_row_costs_its_own_edges_not_the_batch(pkg):
         off += n
 
 
+def test_long_overflow_lists_and_neighbouring_hub_rows(pkg):
+    """The whole-wave gather of a hub row: lists of several rounds (a degree-100 node: 12 overflow blocks), several hub
+    rows among the sixteen rows one wave owns in a pass (nodes 16..19), the last row of a graph (whose clamped
+    duplicates in the passes beyond n must not add twice), and a hub in a graph smaller than the batch's largest."""
+    T, cfg, net, embed, opt, params = model(pkg, 500)
+    g1 = with_hub(1000, 7, 811, 100)
+    for i, hubnode in enumerate((16, 17, 18, 19)):
+        rng = np.random.RandomState(900 + i)
+        for v in rng.permutation(1000):
+            if g1.degree(hubnode) >= 20 + 9 * i:
+                break
+            if int(v) != hubnode and not g1.has_edge(hubnode, int(v)):
+                g1.add_edge(hubnode, int(v), weight=1, capacity=1)
+    g2 = with_hub(776, 7, 812, 30, hub=775)
+    graphs = {0: R.regular_graph(1000, 7, 813), 1: g1, 2: g2}
+    ds = util.dataset_of(graphs, terms_for(graphs))
+    host = pkg.graph.BatchArrays([it[0] for it in ds.values()])
+    assert host.ell_width == 8 and host.max_degree >= 100 and int(host.ovf_ptr[-1]) >= 12 + 4 * 2 + 3
+    eng, tags = util.check_step_against_oracle(pkg, net, ds, params)
+    assert set(tags) == FUSED, tags
+
+
+def test_more_overflow_blocks_than_threads_in_one_graph(pkg, monkeypatch):
+    """A caller of the C ABI may hand over any table / overflow split.  Force a 16-slot table onto dense G(n,p) graphs
+    (the host layer would pick the row kernels): ~45 neighbours per row -> 4 blocks per row, > 1,024 blocks per graph -
+    the commit's copy loop beyond a thread's first block - on the fused kernels (small graphs leave the LDS for it)."""
+    T, cfg, net, embed, opt, params = model(pkg, 64)
+    monkeypatch.setattr(pkg.graph.BatchArrays, "choose_width", staticmethod(lambda degi: 16))
+    graphs = {0: gnp(300, 0.15, 21), 1: gnp(280, 0.12, 22)}
+    ds = util.dataset_of(graphs, terms_for(graphs))
+    host = pkg.graph.BatchArrays([it[0] for it in ds.values()])
+    assert host.ell_width == 16 and 1024 < host.ovf_max_blocks <= 4095, host.ovf_max_blocks
+    eng, tags = util.check_step_against_oracle(pkg, net, ds, params)
+    assert set(tags) == FUSED, tags
+
+
 def test_gnp_graphs_with_overflow_rows_on_the_16_slot_path(pkg):
     """G(n,p) graphs (GraphCreator 'prob'): Poisson-like degrees, a few rows beyond 16 -> 16-slot table + overflow."""
     T, cfg, net, embed, opt, params = model(pkg, 500)
