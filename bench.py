@@ -133,6 +133,12 @@ def generate(specs):
     touches the GPU (forked workers and an initialised HIP runtime do not mix)."""
     import multiprocessing as mp
     workers = max(1, min(8, (os.cpu_count() or 2) // 2, len(specs)))
+    # Under a counter-collecting profiler (rocprofv3 --pmc) the profiler's preloaded library has initialised the GPU
+    # before this program's first line: forked workers then hang now and then (two of two passes of this round, on
+    # exit).  Generate in this process there - a profiled run is not timed from the outside.
+    if os.environ.get("GCN_MAXCUT_BENCH_SERIAL_GEN") == "1" or "rocprof" in os.environ.get("LD_PRELOAD", "").lower() \
+            or any(k.startswith("ROCPROFILER_") or k.startswith("ROCPROF_") for k in os.environ):
+        workers = 1
     if workers == 1:
         return [_make_graph(sp) for sp in specs]
     with mp.get_context("fork").Pool(workers) as pool:
@@ -228,8 +234,12 @@ def main():
         for _name, kind, par, base, _what in extra_defs:
             specs += [(kind, n, par, base + i) for i in range(n_other)]
     t_gen = time.perf_counter()
+    if rank == 0:
+        print(f"[bench] generating {len(specs)} graphs", file=sys.stderr, flush=True)
     made = generate(specs)
     t_gen = time.perf_counter() - t_gen
+    if rank == 0:
+        print(f"[bench] graphs generated in {t_gen:.1f} s", file=sys.stderr, flush=True)
     graphs = dict(enumerate(made[:gpg]))
     terms = {i: terminals_of(n, s) for i, s in enumerate(seeds)}
 

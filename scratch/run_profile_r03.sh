@@ -3,6 +3,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export GCN_MAXCUT_BENCH_SERIAL_GEN=1   # no forked graph-generation workers under the profiler (they hang now and then once its library has initialised the GPU)
 PASS=${1:-stats}
 TAG=${2:-r03a}
 SMALL="--steps 5 --warmup 1 --no-cpu-baseline --no-sequential --no-other-workloads --no-dp-profile"

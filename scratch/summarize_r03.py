@@ -60,8 +60,10 @@ with open(f"profiles/{rnd}_bench_kernel_stats_timed_region.csv", "w") as out:
     shapes = (("fwd1_lds_kernel<16, 8, 4, false, 7, false>", 256), ("head_kernel", B),
               ("bwd1_reg_kernel<16, 4, false, 7, false>", 256), ("finish_kernel", 489))
     step_rows = []
+    exact = {}   # the timed region's instantiation of each kernel (the reference-schedule region launches finish_kernel<1> on the same grid)
     for key, wgs in shapes:
         mine = [r for r in rows_t if key in r["Kernel_Name"] and workgroups(r) == wgs][-K:]
+        exact[key] = mine[-1]["Kernel_Name"]
         step_rows += mine
         v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in mine]
         w.writerow([short(mine[-1]["Kernel_Name"]), wgs, len(v), f"{sum(v)/len(v):.2f}", f"{min(v):.2f}", f"{max(v):.2f}"])
@@ -70,7 +72,7 @@ with open(f"profiles/{rnd}_bench_kernel_stats_timed_region.csv", "w") as out:
     # the launches bench.py's HIP events bracket (`kernels_ms`, `roofline`): the probe region = the FIRST launches of
     # these shapes in the process, 150 untimed steps then K probed ones
     for key, wgs in shapes:
-        mine = [r for r in rows_t if key in r["Kernel_Name"] and workgroups(r) == wgs][150:150 + K]
+        mine = [r for r in rows_t if r["Kernel_Name"] == exact[key] and workgroups(r) == wgs][150:150 + K]
         v = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in mine]
         tag_ = {"fwd1": "fwd1_fused", "head": "head", "bwd1": "bwd1_fused", "fini": "finish"}[key[:4]]
         w.writerow([short(mine[-1]["Kernel_Name"]) + " - the K launches of the probe region (HIP events of the same run: "
