@@ -478,83 +478,49 @@ __device__ __forceinline__ unsigned ovf_desc(const OvfLds &o, int l) {
 // (Round 3, first version: the row's own four lanes walked the list, two tile reads per step of a dependent chain -
 // 2,400 cycles per gather for a degree-40 row with everybody else at the barrier: the workgroup that met the ONE
 // hub row of a 160-graph batch took 150 us, the others 110.)
-// (NR rows at once: their hops travel together - with G(n,p)-like tails the fullest wave of a workgroup has ~5 hub
-// rows per gather and the other fifteen wait for it; two at a time is 3 serial chains instead of 5.)
-template <int FS, int WT, int NR>
-__device__ __forceinline__ void gather_hub_rows_wave(const float *tile, const unsigned short *nb, const OvfLds &o, const int (&l)[NR],
-                                                     const unsigned (&d)[NR], int q, int zero_row, float4 (&out)[NR]) {
+template <int FS, int WT>
+__device__ __forceinline__ float4 gather_hub_row_wave(const float *tile, const unsigned short *nb, const OvfLds &o, int l, unsigned d, int q,
+                                                      int zero_row) {
     constexpr int Q = FS / 4, J = 64 / Q;
     typedef float v4f __attribute__((ext_vector_type(4)));
     using lds_f4 = __attribute__((address_space(3))) const v4f;
     using lds_u16 = __attribute__((address_space(3))) const unsigned short;
     const unsigned j = (threadIdx.x & 63u) / Q;
+    const unsigned ne = (unsigned)WT + 8u * (d >> 12);      // list entries (the last block's padding ids = zero row)
+    const unsigned ids = o.blocks + 16u * (d & 0xfffu);
+    const unsigned tab = WT > 0 ? (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short *)nb + 2u * (unsigned)(l * WT) : 0u;
     const unsigned tile_q = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)tile + 16u * (unsigned)q;
-    unsigned ne[NR], ids[NR], tab[NR], id[NR], ne_max = 0;
-    v4f acc[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        // list entries (the last block's padding ids = zero row); a row slot without a row (d == 0): none
-        ne[r] = d[r] ? (unsigned)WT + 8u * (d[r] >> 12) : 0u;
-        ne_max = max(ne_max, ne[r]);
-        ids[r] = o.blocks + 16u * (d[r] & 0xfffu);
-        tab[r] = WT > 0 ? (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned short *)nb + 2u * (unsigned)(l[r] * WT) : 0u;
-        acc[r] = (v4f)(0.f);
-    }
-    auto id_of = [&](int r, unsigned e) {
-        const unsigned ec = min(e, max(ne[r], 1u) - 1u);
-        const unsigned addr = ec < (unsigned)WT ? tab[r] + 2u * ec : ids[r] + 2u * (ec - (unsigned)WT);
+    auto id_of = [&](unsigned e) {
+        const unsigned ec = min(e, ne - 1u);
+        const unsigned addr = ec < (unsigned)WT ? tab + 2u * ec : ids + 2u * (ec - (unsigned)WT);
         return (unsigned)*(lds_u16 *)(size_t)addr;
     };
-#pragma unroll
-    for (int r = 0; r < NR; ++r) id[r] = id_of(r, j);
+    v4f acc = (v4f)(0.f);
+    unsigned id = id_of(j);
 #pragma unroll 1
-    for (unsigned e0 = 0; e0 < ne_max; e0 += J) {           // (wave-uniform trip count)
-        unsigned cur[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) cur[r] = e0 + j < ne[r] ? id[r] : (unsigned)zero_row;
-        if (e0 + J < ne_max) {                              // next round's ids travel with this round's tile reads
-#pragma unroll
-            for (int r = 0; r < NR; ++r) id[r] = id_of(r, e0 + J + j);
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) acc[r] += *(lds_f4 *)(size_t)(tile_q + cur[r] * (unsigned)(FS * 4));
+    for (unsigned e0 = 0; e0 < ne; e0 += J) {               // (wave-uniform trip count)
+        const unsigned cur = e0 + j < ne ? id : (unsigned)zero_row;
+        if (e0 + J < ne) id = id_of(e0 + J + j);            // next round's ids travel with this round's tile reads
+        acc += *(lds_f4 *)(size_t)(tile_q + cur * (unsigned)(FS * 4));
     }
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-        out[r] = make_float4(gmc::xor_tree<32, Q>(acc[r].x), gmc::xor_tree<32, Q>(acc[r].y), gmc::xor_tree<32, Q>(acc[r].z), gmc::xor_tree<32, Q>(acc[r].w));
+    return make_float4(gmc::xor_tree<32, Q>(acc.x), gmc::xor_tree<32, Q>(acc.y), gmc::xor_tree<32, Q>(acc.z), gmc::xor_tree<32, Q>(acc.w));
 }
 // For every DISTINCT hub row among this wave's rows of one pass (d_mine: my row's descriptor, 0 = no overflow blocks -
 // read by the caller for all its rows at once; l_mine: my row): f(l, t) with the row l (wave-uniform) and its overflow
 // sum t (for my q; WT > 0: the row's table slots included) - callers pick it up where l == l_mine and do everything
-// else (read-modify-writes, stores) OUTSIDE, for all their hub rows in parallel: the loop is a serial chain per PAIR of
-// hub rows, and with 2-3 % hub rows (G(n,p) tails) the fullest wave of a workgroup has five while fifteen others wait
-// at the barrier.  Runs on scalar branches: a wave without hub rows in the pass falls through.
-#ifndef GMC_OVF_ROWS_AT_ONCE
-#define GMC_OVF_ROWS_AT_ONCE 2
-#endif
+// else (read-modify-writes, stores) OUTSIDE, for all their hub rows in parallel: the loop is a serial chain per hub row, and with 2-3 %
+// hub rows (G(n,p) tails) the fullest wave of a workgroup walks it five times while fifteen others wait at the barrier.
+// Runs on scalar branches: a wave without hub rows in the pass falls through.
 template <int FS, int WT, typename F>
 __device__ __forceinline__ void for_hub_rows(unsigned d_mine, int l_mine, int q, const float *tile, const unsigned short *nb, const OvfLds &o,
                                              int zero_row, F &&f) {
-    constexpr int NR = GMC_OVF_ROWS_AT_ONCE;
     unsigned long long m = __builtin_amdgcn_ballot_w64(d_mine != 0);
     while (m) {
-        int l[NR];
-        unsigned d[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            l[r] = 0; d[r] = 0;
-            if (m) {   // (scalar)
-                const int src = __builtin_ctzll(m);
-                l[r] = __builtin_amdgcn_readlane(l_mine, src);
-                d[r] = (unsigned)__builtin_amdgcn_readlane((int)d_mine, src);
-                m &= ~__builtin_amdgcn_ballot_w64(l_mine == l[r]);   // every lane of the row (and its clamped duplicates) at once
-            }
-        }
-        float4 t[NR];
-        gather_hub_rows_wave<FS, WT, NR>(tile, nb, o, l, d, q, zero_row, t);
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (d[r]) f(l[r], t[r]);   // (scalar)
+        const int src = __builtin_ctzll(m);
+        const int l = __builtin_amdgcn_readlane(l_mine, src);
+        const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)d_mine, src);
+        m &= ~__builtin_amdgcn_ballot_w64(l_mine == l);     // every lane of the row (and its clamped duplicates) at once
+        f(l, gather_hub_row_wave<FS, WT>(tile, nb, o, l, d, q, zero_row));
     }
 }
 
