@@ -157,15 +157,20 @@ def terminals_of(n, seed):
 
 
 def csrc_fingerprint():
-    """sha256 over the kernel sources: profiles/traffic_*.json carry the fingerprint they were measured on, and a
-    PMC figure is quoted only for the sources it belongs to."""
+    """sha256 over the kernel sources' CODE (comments and blank lines dropped): profiles/traffic_*.json carry the
+    fingerprint they were measured on, and a PMC figure is quoted only for the code it belongs to."""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "gcn-max-cut_amd", "csrc", "*.hip")) +
                     glob.glob(os.path.join(ROOT, "gcn-max-cut_amd", "csrc", "*.h"))):
+        text = open(f, "r", encoding="utf-8").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)                       # block comments
+        text = re.sub(r"//[^\n]*", "", text)                                    # line comments (no '//' inside the kernels' strings)
+        code = "\n".join(ln.rstrip() for ln in text.splitlines() if ln.strip())
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(code.encode())
     return h.hexdigest()[:16]
 
 

@@ -352,13 +352,13 @@ __device__ __forceinline__ float4 gather_row(const float *tile, const unsigned s
 // eight ids per block, padded with the zero row).  Only the OVF instantiations of the fused kernels carry this.
 // Everything a gather needs lives in the LDS the launch has left over behind the kernel's own regions (a few KB):
 //   desc[n_max]  one 16-bit word per row: (blocks << 12) | first block relative to the graph's first; 0 = none (97-100 %
-//                of the rows) - ONE ds_read_u16 per row and gather tells, no register is held across the slice loop;
-//   blocks[cap]  the graph's first `cap` blocks of eight ids (the rest, if any, is read from L2).
-// Nothing of it may sit in registers or be reached through generic pointers: the OVF kernels' first versions kept a
-// row's (start, count) in registers / called a helper - 300-500 B of scratch per lane, and every spill reload (and
-// every flat load) inside a gather is a vector-memory operation the compiler fences with vmcnt(0), i.e. a wait for the
-// tile DMA in flight behind the gather: ONE hub row in ONE graph of 160 made the step 2.3x slower (219 / 267 us
-// against 88 / 112), a G(n, p = 0.01) batch 4.3x (scratch/ovf_probe.py, profiles/r03_ablation.json).
+//                of the rows);
+//   blocks[cap]  the graph's blocks of eight ids (gmc_lds_fits admits a batch only if every graph's blocks fit).
+// A thread keeps its rows' descriptors (or one bit per row) in registers; the lists themselves are reached through
+// LDS-address-space pointers only.  No global load, no spill reload and no flat load may sit on any path of a gather:
+// each is a vector-memory operation the compiler fences with vmcnt(0), i.e. a wait for the tile DMA in flight behind
+// the gather - in the OVF kernels' first versions ONE hub row in ONE graph of 160 made the step 2.3x slower (219 /
+// 267 us against 88 / 112), a G(n, p = 0.01) batch 4.3x (scratch/ovf_probe.py, profiles/r03_ablation.json).
 struct OvfLds {
     unsigned desc;    // LDS byte address of desc[]
     unsigned blocks;  // LDS byte address of blocks[]
