@@ -85,7 +85,7 @@ bool use_lds(const gmc_batch *b, const gmc_model *m) {
     }();
     if (forced == 1) return false;
 #endif
-    if (b->ovf_ptr && (!fuse_enabled() || (m && m->dropout_p > 0.f))) return false;
+    if (gmc_has_overflow(b) && (!fuse_enabled() || (m && m->dropout_p > 0.f))) return false;
     return gmc_lds_fits(b);
 }
 

@@ -679,7 +679,7 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     const int grid = a.slices * a.chunks;
     const bool hv = a.b.ell_vals != nullptr;
     const int ns = ns_class(W, a.b.ell_slots, !hv);   // live slots: no row of the batch has more neighbours
-    const bool ov = a.b.ovf_ptr != nullptr;   // hub rows: every slot live, overflow lists walked
+    const bool ov = gmc_has_overflow(&a.b);   // hub rows: every slot live, overflow lists walked
     if constexpr (W == 8) {
 #define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_reg_kernel<FS, 4, HV, NSK, OV>, grid, lds, st, a) \
                                         : launch(bwd1_reg_kernel<FS, 8, HV, NSK, OV>, grid, lds, st, a))
@@ -707,7 +707,7 @@ int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, co
     const int fs = pick_fs(b->n_max, b->ell_width);
     Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk, 0, 0};
     size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
-    if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graphs' first overflow blocks
+    if (gmc_has_overflow(b)) {   // hub rows: all of the CU's LDS, the spare holds the graphs' first overflow blocks
         const size_t own = ovf_own_bytes(1, b->n_max, b->ell_width, fs);
         if (own + ovf_desc_bytes(b->n_max) > kOvfLdsBytes) return GMC_ERR_UNSUPPORTED;   // (gmc_lds_fits says so beforehand)
         a.own_lds = (int)own;

@@ -337,7 +337,7 @@ int launch_fwd1(const TileArgs &a, size_t lds, int grid, hipStream_t st) {
     const int ns = ns_class(W, a.b.ell_slots, !a.use_vals);
 #define GMC_FWD1(AC, HV, NSK, OV) launch(fwd1_lds_kernel<FS, W, AC, HV, NSK, OV>, grid, lds, st, a)
 #define GMC_FWD1_ACC(HV, NSK, OV) (acc <= 4 ? GMC_FWD1(4, HV, NSK, OV) : GMC_FWD1(8, HV, NSK, OV))
-    if (a.b.ovf_ptr) {   // hub rows: every slot live (weights + overflow: row kernels, see gmc_lds_fits)
+    if (gmc_has_overflow(&a.b)) {   // hub rows: every slot live (weights + overflow: row kernels, see gmc_lds_fits)
         if (a.use_vals) return GMC_ERR_UNSUPPORTED;
         return GMC_FWD1_ACC(false, W, true);
     }
@@ -371,7 +371,7 @@ int gmc_fwd1_lds_launch(const gmc_batch *b, const float *W1, const float *b1, co
                F, slices, groups, W2, Zpart, ipw, 0, 0, 0, 0};
     if (W1_slab) { a.X = W1_slab; a.x_rs = 16; a.x_slab16 = 1; a.x_rows = N; }
     size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
-    if (b->ovf_ptr) {   // hub rows: all of the CU's LDS, the spare holds the graph's first overflow blocks
+    if (gmc_has_overflow(b)) {   // hub rows: all of the CU's LDS, the spare holds the graph's first overflow blocks
         const size_t own = ovf_own_bytes(0, b->n_max, b->ell_width, fs);
         if (own + ovf_desc_bytes(b->n_max) > kOvfLdsBytes) return GMC_ERR_UNSUPPORTED;   // (gmc_lds_fits says so beforehand)
         a.own_lds = (int)own;

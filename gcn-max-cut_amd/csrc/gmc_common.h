@@ -29,6 +29,10 @@ int gmc_spmm_launch(const int32_t *rowptr, const int32_t *col, const float *vals
                     int tag, hipStream_t st);
 
 static inline bool gmc_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// does the batch carry overflow lists the LDS-tiled kernels have to walk?  (ovf_ptr without a single block - the host
+// says so through ovf_max_blocks, the pointers are device memory - is a batch without lists: the OVF kernels read
+// block 0 of the batch unconditionally for a graph that has none.)
+static inline bool gmc_has_overflow(const gmc_batch *b) { return b->ovf_ptr != nullptr && b->ovf_ids != nullptr && b->ovf_max_blocks > 0; }
 
 namespace gmc {
 

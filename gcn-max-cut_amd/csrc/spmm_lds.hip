@@ -351,7 +351,7 @@ bool gmc_lds_fits(const gmc_batch *b) {
     // overflow lists: their per-row descriptors have to fit behind the fused kernels' own LDS (n <= ~1004 with 8-slot
     // tables at 16-column tiles; larger graphs with hub rows take the row kernels)
     // (and no edge weights: the overflow blocks' weights would have to be read from global memory inside a gather)
-    return !b->ovf_ptr || (!b->ell_vals && ovf_fits(b->n_max, b->ell_width, fs, b->ovf_max_blocks));
+    return !gmc_has_overflow(b) || (!b->ell_vals && ovf_fits(b->n_max, b->ell_width, fs, b->ovf_max_blocks));
 }
 
 bool gmc_bwd1_fits(const gmc_batch *b) { return gmc_lds_fits(b); }
@@ -400,7 +400,7 @@ int gmc_spmm_lds_launch(const gmc_batch *b, const float *X, long ldx, int x_slab
     if (!b || !X || !Y) return GMC_ERR_NULL;
     if (F % 4 || ldx % 4 || ldy % 4 || !gmc_aligned16(X) || !gmc_aligned16(Y))
         return GMC_ERR_ALIGN;
-    if (!gmc_lds_fits(b) || b->ovf_ptr) return GMC_ERR_UNSUPPORTED;   // (overflow lists: the fused kernels walk them)
+    if (!gmc_lds_fits(b) || gmc_has_overflow(b)) return GMC_ERR_UNSUPPORTED;   // (overflow lists: the fused kernels walk them)
     if (b->B == 0) return GMC_OK;
     const int fs = pick_fs(b->n_max, b->ell_width);
     const long slab_ss = (long)b->R * fs;
@@ -444,7 +444,7 @@ int device_cus(bool allow_override) {
 // dW1 partials: out[chunk][v][:] = sum_{g in chunk} sum_e vals[e] * U[g][nbr(e), :], v < n_max
 int gmc_dw1_lds_launch(const gmc_batch *b, const float *U, long ldu, int u_slab, float *out, int F, int chunks,
                        int graphs_per_chunk, hipStream_t st) {
-    if (!gmc_lds_fits(b) || b->ovf_ptr) return GMC_ERR_UNSUPPORTED;
+    if (!gmc_lds_fits(b) || gmc_has_overflow(b)) return GMC_ERR_UNSUPPORTED;
     const int fs = pick_fs(b->n_max, b->ell_width);
     Dw1TileArgs a{*b, U, u_slab ? fs : ldu, u_slab ? (long)b->R * fs : fs, out, F, (F + fs - 1) / fs, chunks,
                   graphs_per_chunk};

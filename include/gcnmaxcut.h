@@ -83,9 +83,10 @@ typedef struct gmc_batch {
     /* Overflow lists (NULL: no row of the batch has more than ell_width neighbours): the neighbours of row r
      * beyond its first ell_width, CSR order, in blocks of 8 local ids - blocks ovf_ptr[r] .. ovf_ptr[r+1]-1,
      * i.e. ids ovf_ids[8*ovf_ptr[r] ..), the last block of a row padded with n_g (weight 0).  A row with a
-     * hub's degree then costs its own extra blocks (a short tail loop of the thread that owns the row)
-     * instead of moving the whole batch to the row kernels.  Summation order of a row: ELL slots, then the
-     * overflow blocks in order. */
+     * hub's degree then costs its own extra blocks (gathered by the wave that owns the row) instead of moving
+     * the whole batch to the row kernels.  Summation order of a row: fixed (ELL slots and block entries dealt
+     * over the lanes of a wave, then a butterfly), bitwise reproducible.  ovf_ptr with ovf_max_blocks == 0 (or
+     * ovf_ids == NULL) is a batch without lists. */
     const int32_t *ovf_ptr;   /* [R+1] in blocks, or NULL */
     const uint16_t *ovf_ids;  /* [8 * ovf_ptr[R]] */
     const float *ovf_vals;    /* [8 * ovf_ptr[R]] or NULL when all ones */

@@ -136,6 +136,26 @@ def test_more_overflow_blocks_than_threads_in_one_graph(pkg, monkeypatch):
     assert set(tags) == FUSED, tags
 
 
+def test_overflow_pointer_without_blocks_is_a_batch_without_lists(pkg, monkeypatch):
+    """C-ABI callers may hand over `ovf_ptr` (all zeros) with `ovf_max_blocks == 0` and no `ovf_ids`: the library treats
+    it as a batch without lists (plain fused kernels; the OVF flavours would read block 0 of the batch)."""
+    T, cfg, net, embed, opt, params = model(pkg, 64)
+    orig = pkg.graph.BatchArrays.__init__
+
+    def init(self, *a, **k):
+        orig(self, *a, **k)
+        assert self.ovf_ptr is None
+        self.ovf_ptr = np.zeros(self.R + 1, np.int32)
+        self.ovf_ids = self.ovf_vals = None
+        self.ovf_max_blocks = 0
+
+    monkeypatch.setattr(pkg.graph.BatchArrays, "__init__", init)
+    graphs = {0: R.regular_graph(300, 7, 31), 1: R.regular_graph(200, 8, 32)}
+    ds = util.dataset_of(graphs, terms_for(graphs))
+    eng, tags = util.check_step_against_oracle(pkg, net, ds, params)
+    assert set(tags) == FUSED, tags
+
+
 def test_gnp_graphs_with_overflow_rows_on_the_16_slot_path(pkg):
     """G(n,p) graphs (GraphCreator 'prob'): Poisson-like degrees, a few rows beyond 16 -> 16-slot table + overflow."""
     T, cfg, net, embed, opt, params = model(pkg, 500)
