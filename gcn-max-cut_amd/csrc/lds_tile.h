@@ -383,6 +383,7 @@ inline size_t ovf_own_bytes(int kernel, int n_max, int W, int FS) {
 // gathers must not contain a single global load, not even on a rare path: the compiler closes a branch that holds
 // one with s_waitcnt vmcnt(0) at the join, which every row then executes - a wait for the tile DMA in flight.)
 inline bool ovf_fits(int n_max, int W, int FS, int max_blocks) {
+    if (max_blocks > kOvfMaxBlocksPerGraph) return false;   // (small graphs leave LDS for more than a descriptor can address)
     for (int kernel = 0; kernel < 2; ++kernel) {
         const size_t own = ovf_own_bytes(kernel, n_max, W, FS);
         if (own + ovf_desc_bytes(n_max) > kOvfLdsBytes || ovf_cap_blocks(own, n_max) < max_blocks) return false;
