@@ -238,6 +238,10 @@ def main():
                        "(GraphCreator 'prob'; 16-slot table + overflow lists for the rows beyond 16)")]
         for _name, kind, par, base, _what in extra_defs:
             specs += [(kind, n, par, base + i) for i in range(n_other)]
+        # BASELINE configs[1]: a batch of 20 x n = 500 graphs of degree 6..8 (the reference pipeline's own mix,
+        # GraphCreator.py:151-152) - half-size graphs run the 32-column tiles
+        c1_n, c1_count = max(50, n // 2), min(20, n_other)
+        specs += [("reg", c1_n, 6 + i % 3, 30000 + i) for i in range(c1_count)]
     t_gen = time.perf_counter()
     if rank == 0:
         print(f"[bench] generating {len(specs)} graphs", file=sys.stderr, flush=True)
@@ -404,11 +408,14 @@ def main():
     if extras_on:
         other = {}
         off = gpg
-        for name, kind, par, base, what in extra_defs:
-            gl = dict(enumerate(made[off:off + n_other]))
-            off += n_other
+        runs = [(name, what, n, n_other, base) for name, _kind, _par, base, what in extra_defs]
+        runs.append(("c1_20x500_d6to8", f"{c1_count} x n={c1_n} regular graphs of degree 6, 7, 8 (BASELINE configs[1]; one batched "
+                     "step per epoch of 20 graphs)", c1_n, c1_count, 30000))
+        for name, what, n_o, count_o, base in runs:
+            gl = dict(enumerate(made[off:off + count_o]))
+            off += count_o
             try:   # (an extra: must not cost the run its headline)
-                ds_o = extend(gl, {i: terminals_of(n, base + i) for i in gl})
+                ds_o = extend(gl, {i: terminals_of(n_o, base + i) for i in gl})
                 net_o, embed_o, opt_o = fresh_model()
                 tr_o = T.FusedTrainer(net_o, opt_o, cfg, graphs_per_step=len(ds_o), local_shard=True)
                 k_o = max(20, args.steps // 2)

@@ -1005,7 +1005,8 @@ def test_bench_line_contract(pkg):
     assert c["gpu_sequential_over_cpu"] > 0 and c["gpu_sequential_over_cpu_variant_B"] > 0
     # other degrees / graph families on the same fused kernels, each with its parity gate
     ow = d["other_workloads"]
-    assert set(ow) == {"d8", "d12", "gnp"}
+    assert set(ow) == {"d8", "d12", "gnp", "c1_20x500_d6to8"}
+    assert ow["c1_20x500_d6to8"]["table_slots"] == 8 and ow["c1_20x500_d6to8"]["max_degree"] == 8
     assert (ow["d8"]["table_slots"], ow["d8"]["live_slots"]) == (8, 8) and ow["d8"]["overflow_blocks"] == 0
     assert (ow["d12"]["table_slots"], ow["d12"]["live_slots"]) == (16, 12) and ow["d12"]["overflow_blocks"] == 0
     assert ow["gnp"]["table_slots"] == 16 and ow["gnp"]["overflow_blocks"] > 0 and ow["gnp"]["max_degree"] > 16
