@@ -263,6 +263,34 @@ def test_bench_launcher_refuses_cleanly_without_gpus():
     assert out.returncode == 2 and "refusing to launch" in out.stderr and out.stdout.strip() == ""
 
 
+def test_bench_helpers_fingerprint_and_graph_generation(monkeypatch, tmp_path):
+    """`bench.csrc_fingerprint` names the kernel sources' CODE (the PMC records under profiles/ are quoted only while
+    it matches): comments and blank lines do not move it, a code edit does.  `bench.generate` stays in-process under a
+    profiler (forked workers hang once its library has initialised the GPU) and returns the same graphs either way."""
+    import importlib, shutil, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    fp = bench.csrc_fingerprint()
+    copy_root = tmp_path / "repo"
+    shutil.copytree(os.path.join(root, "gcn-max-cut_amd", "csrc"), copy_root / "gcn-max-cut_amd" / "csrc",
+                    ignore=shutil.ignore_patterns("build*", "*.o"))
+    monkeypatch.setattr(bench, "ROOT", str(copy_root))
+    assert bench.csrc_fingerprint() == fp
+    f = copy_root / "gcn-max-cut_amd" / "csrc" / "head.hip"
+    text = f.read_text()
+    f.write_text("// a new comment\n\n/* and a block\n   comment */\n" + text.replace("// Per-graph", "//  Per-graph (edited)", 1))
+    assert bench.csrc_fingerprint() == fp
+    f.write_text(text.replace("constexpr int kHeadThreads = 1024;", "constexpr int kHeadThreads = 512;", 1))
+    assert bench.csrc_fingerprint() != fp
+    specs = [("reg", 40, 5, 7), ("gnp", 40, 0.2, 8), ("reg", 30, 4, 9)]
+    monkeypatch.setenv("GCN_MAXCUT_BENCH_SERIAL_GEN", "1")
+    serial = bench.generate(specs)
+    monkeypatch.delenv("GCN_MAXCUT_BENCH_SERIAL_GEN")
+    forked = bench.generate(specs)
+    assert [sorted(g.edges()) for g in serial] == [sorted(g.edges()) for g in forked]
+
+
 def test_sampler_semantics_are_numpy_version_independent(built, monkeypatch):
     """assign_partitions (TestingNeuralNetwork.py:18-46): host form and oracle use the pinned NumPy 1.x
     arithmetic (float64 running sum and compare) whatever NumPy is installed; on draws one ulp either side of
