@@ -21,8 +21,12 @@ int gmc_finish_launch(const float *, const float *, const float *, int, int, int
 int gmc_loss_tail_launch(const float *, int, float *, hipStream_t);
 int gmc_fwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int,
                         hipStream_t, const float *, int);
+struct gmc_bwd1_head {   // (bwd1_lds.hip) the head's arguments for a backward launch that computes it as well
+    const float *Z0; int zparts; const float *b2; float C; float *P; int *S; float *loss; float *db2part; int *tick;
+};
+bool gmc_bwd1_takes_head(const gmc_batch *b);
 int gmc_bwd1_lds_launch(const gmc_batch *, const float *, const float *, const float *, float *, float *, int, int,
-                        int, hipStream_t);
+                        int, hipStream_t, const gmc_bwd1_head *);
 int gmc_hidden_bwd_launch(const float *, long, const float *, const float *, const float *, float *,
                           long, float *, int, int, hipStream_t);
 int gmc_colsum_reduce_launch(const float *, int, int, float *, float *, const float *, int, float *,
@@ -178,7 +182,8 @@ struct AdamFuse {  // optional Adam fused into the gradient fold (single GPU)
 
 // loss_tail: per-graph losses whose sum goes to the slot after the gradient (GMC_MODEL_GRAD_TAIL), or nullptr
 int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, float *grad,
-                  hipStream_t st, const AdamFuse *af = nullptr, const float *loss_tail = nullptr) {
+                  hipStream_t st, const AdamFuse *af = nullptr, const float *loss_tail = nullptr,
+                  const gmc_bwd1_head *head = nullptr) {
     const long F = m->F;
     float *dW1 = grad, *db1 = grad + (long)m->N * F, *dW2 = db1 + F, *db2 = dW2 + F * 3;
     float *Gs = w.T0, *U = w.H;
@@ -191,7 +196,7 @@ int backward_body(const gmc_batch *b, const gmc_model *m, const Workspace &w, fl
     }
     if (w.fs && fuse_enabled() && gmc_bwd1_fits(b) && !dropout_on(m)) {  // one pass over H: Gs and U live only in LDS
         const int chunks = gmc_dw1_chunks(b->B, true, gmc_lds_slices(b, m->F)), per = (b->B + chunks - 1) / chunks;
-        int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st);
+        int rc = gmc_bwd1_lds_launch(b, w.H, w.GY2, m->W2, w.dw1part, w.part, m->F, chunks, per, st, head);
         if (rc) return rc;
         return gmc_finish_launch(w.dw1part, w.part, w.db2part, chunks, b->n_max, m->N, m->F, b->B, grad,
                                  af ? af->param : nullptr, af ? af->m : nullptr, af ? af->v : nullptr,
@@ -371,14 +376,20 @@ extern "C" int gmc_train_step_f32(const gmc_batch *batch, int32_t N, int32_t F, 
     }
     rc = forward_body(batch, &model, w, st);
     if (rc) return rc;
-    // the head launch advances the step counter for the fused Adam of the finish kernel
-    rc = gmc_head_launch(batch, w.Z0, w.zparts, model.b2, C, P, S, loss, w.GY2, w.db2part, step_counter, st);
-    if (rc) return rc;
+    // One graph per step (the reference's own schedule): the backward launch computes the head as well - every one of
+    // its workgroups for itself, the rows (GY2, dinv) never leave the CU - three launches per graph-step instead of four
+    const bool head_in_bwd = gmc_bwd1_takes_head(batch) && gmc_dw1_chunks(batch->B, true, gmc_lds_slices(batch, F)) == 1;
+    // the head (launch) advances the step counter for the fused Adam of the finish kernel
+    if (!head_in_bwd) {
+        rc = gmc_head_launch(batch, w.Z0, w.zparts, model.b2, C, P, S, loss, w.GY2, w.db2part, step_counter, st);
+        if (rc) return rc;
+    }
     AdamFuse af;
     af.param = param; af.m = mom; af.v = var; af.lr = lr; af.beta1 = beta1; af.beta2 = beta2; af.eps = eps;
     af.step_counter = step_counter;
     af.w1_slab = w1_slab;
-    return backward_body(batch, &model, w, grad, st, &af);
+    const gmc_bwd1_head hd{w.Z0, w.zparts, model.b2, C, P, S, loss, w.db2part, step_counter};
+    return backward_body(batch, &model, w, grad, st, &af, nullptr, head_in_bwd ? &hd : nullptr);
 }
 
 extern "C" int gmc_backward_from_gp(const gmc_batch *batch, const gmc_model *model, void *workspace,

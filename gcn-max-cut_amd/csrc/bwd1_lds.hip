@@ -1,10 +1,15 @@
 // Fused layer-1 backward of the GCN (autograd of TrainingNeural.py:80-83, run by loss.backward() :385)
 // for graphs that fit a CU's LDS.  Shared tile machinery: lds_tile.h.
 #include "lds_tile.h"
+#include "head_body.h"
 
 #ifdef GMC_STAMP
 extern "C" int gmc_debug_read_stamps_bwd(unsigned long long *out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+// (the head's marks when it runs inside this translation unit's one-graph backward)
+extern "C" int gmc_debug_read_stamps_bwdhead(unsigned long long *out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hstamps), sizeof(unsigned long long) * n);
 }
 #endif
 
@@ -33,6 +38,17 @@ struct Bwd1Args {
     int graphs_per_chunk;
     int ovf_cap;          // OVF kernels: overflow blocks that fit into the LDS behind the kernel's regions ...
     int own_lds;          // ... which end at this byte offset
+    // HEAD kernels (one-graph launches of the reference schedule): the head's arguments - every workgroup computes the
+    // graph's head itself, its (GY2, dinv) rows land in the row-constant LDS region and GY2 above is not read
+    const float *hZ0;     // [zparts][R][3] slice-group partials of the forward
+    int hzparts;
+    float hC;
+    const float *hb2;
+    float *hP;
+    int *hS;
+    float *hloss;
+    float *hdb2part;
+    int *htick;
 };
 
 // per-thread state shared by the two kernel flavours: my 4 columns as two pairs p = (f0+2p, f0+2p+1) -
@@ -144,7 +160,10 @@ __device__ __forceinline__ void dma_row_consts(const float *GY2, int r0, int n, 
 //   (Tried and dropped, measured same-box: pulling the H tile of graph g+2 into L2 with 4-byte LDS-DMA
 //   touches while the tile of g+1 streams in, so that the DMA runs at L2 latency - the kernel got 11 %
 //   SLOWER.)
-template <int FS, int ACC, bool HAS_VAL, int NS, bool OVF>
+// HEAD: a one-graph launch that also computes the graph's head (head_body.h), in every workgroup: no head launch, no
+// launch boundary in front of this one, and the H loads of the prologue travel while the head's fold waits for its
+// partials.  Workgroup 0 stores the head's outputs (P, S, loss, db2 partial, step counter).
+template <int FS, int ACC, bool HAS_VAL, int NS, bool OVF, bool HEAD = false>
 __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int W = 8;
@@ -280,7 +299,7 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     // graph offsets are scalar loads: each is requested one graph ahead of its first use
     int r0 = a.b.goff[g0], n = a.b.goff[g0 + 1] - r0;
     int nn = g0 + 1 < g1 ? a.b.goff[g0 + 2] - (r0 + n) : 0;   // size of graph g+1 (0: none)
-    dma_row_consts(a.GY2, r0, n, gy0);
+    if constexpr (!HEAD) dma_row_consts(a.GY2, r0, n, gy0);
     if (!kRecycle) fetch_tile(r0, n, KREG);
     load_hreg(r0, n);
     float4 hlast = gmc::f4_zero();
@@ -291,6 +310,13 @@ __global__ GMC_LDS_BOUNDS void bwd1_reg_kernel(Bwd1Args a) {
     }
     load_ids(r0, n);
     if constexpr (ovf) ovf_setup<kOvfRows>(a.b, r0, n, ol);
+    if constexpr (HEAD) {
+        // the graph's head, with the H cells / ids above in flight; its LDS arrays lie in the U tile's buffer (free until
+        // gather #1), its (GY2, dinv) rows go straight into the row-constant region the transforms below read
+        static_assert(kThreads == kHeadThreads && !HAS_VAL && !OVF, "one-graph unit-weight launches only");
+        const HeadArgs ha{a.b, a.hZ0, a.hzparts, a.hb2, a.hC, a.hP, a.hS, a.hloss, nullptr, a.hdb2part, a.htick};
+        head_body<8>(ha, g0, bufB, blockIdx.x == 0, reinterpret_cast<float4 *>(gy0));
+    }
     zero_pads(bufA, n);
     dma_wait();
     __syncthreads();
@@ -681,6 +707,10 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
     const int ns = ns_class(W, a.b.ell_slots, !hv);   // live slots: no row of the batch has more neighbours
     const bool ov = gmc_has_overflow(&a.b);   // hub rows: every slot live, overflow lists walked
     if constexpr (W == 8) {
+        if (a.hZ0) {   // one graph, unit weights, no lists, n <= 1024 (gmc_bwd1_takes_head): the head rides in this launch
+            return ns == 7 ? launch(bwd1_reg_kernel<FS, 4, false, 7, false, true>, grid, lds, st, a)
+                           : launch(bwd1_reg_kernel<FS, 4, false, 8, false, true>, grid, lds, st, a);
+        }
 #define GMC_BWD1(HV, NSK, OV) (acc <= 4 ? launch(bwd1_reg_kernel<FS, 4, HV, NSK, OV>, grid, lds, st, a) \
                                         : launch(bwd1_reg_kernel<FS, 8, HV, NSK, OV>, grid, lds, st, a))
         if (ov) return hv ? GMC_ERR_UNSUPPORTED : GMC_BWD1(false, 8, true);   // (weights + overflow: row kernels, see gmc_lds_fits)
@@ -700,12 +730,31 @@ int launch_bwd1(const Bwd1Args &a, size_t lds, hipStream_t st) {
 
 // fused layer-1 backward over the slab-layout H: dW1 partials [chunks][n_max][F] and column
 // partials [chunks][F][4] (dW2, db1)
+// Can the fused backward of this batch compute the head as well (gmc_bwd1_head)?  One graph (every launch of the
+// reference's one-step-per-graph schedule), 8-slot table, unit weights, no overflow lists, at most 1024 rows (one row
+// per thread in the head, four passes in the backward), and the head's LDS arrays fit the U tile's buffer.
+bool gmc_bwd1_takes_head(const gmc_batch *b) {
+    if (!b || b->B != 1 || b->ell_width != 8 || b->ell_vals || gmc_has_overflow(b) || !gmc_lds_fits(b)) return false;
+    const int fs = pick_fs(b->n_max, b->ell_width);
+    const int rows_per_pass = kThreads / (fs / 4);
+    if (b->n_max > 4 * rows_per_pass || b->n_max > kHeadThreads) return false;
+    return (size_t)(7 * (b->n_max + 4) + 64) <= tile_floats(b->n_max, fs);
+}
+
+// head != nullptr (only if gmc_bwd1_takes_head): the launch computes the graph's head too and GY2 is not read
+struct gmc_bwd1_head {
+    const float *Z0; int zparts; const float *b2; float C; float *P; int *S; float *loss; float *db2part; int *tick;
+};
 int gmc_bwd1_lds_launch(const gmc_batch *b, const float *H, const float *GY2, const float *W2,
                         float *dw1part, float *colpart, int F, int chunks, int graphs_per_chunk,
-                        hipStream_t st) {
+                        hipStream_t st, const gmc_bwd1_head *head) {
     if (!gmc_lds_fits(b)) return GMC_ERR_UNSUPPORTED;
+    if (head && (!gmc_bwd1_takes_head(b) || chunks != 1 || !head->Z0 || !head->b2 || !head->P || !head->db2part)) return GMC_ERR_UNSUPPORTED;
     const int fs = pick_fs(b->n_max, b->ell_width);
-    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk, 0, 0};
+    Bwd1Args a{*b, H, GY2, W2, dw1part, colpart, F, (F + fs - 1) / fs, chunks, graphs_per_chunk, 0, 0,
+               head ? head->Z0 : nullptr, head ? head->zparts : 0, head ? head->C : 0.f, head ? head->b2 : nullptr,
+               head ? head->P : nullptr, head ? head->S : nullptr, head ? head->loss : nullptr,
+               head ? head->db2part : nullptr, head ? head->tick : nullptr};
     size_t lds = lds_bytes(b->n_max, b->ell_width, fs);
     if (gmc_has_overflow(b)) {   // hub rows: all of the CU's LDS, the spare holds the graphs' first overflow blocks
         const size_t own = ovf_own_bytes(1, b->n_max, b->ell_width, fs);

@@ -43,6 +43,9 @@ def read(which, count):
 fw = read("fwd", 256 * 256).reshape(256, 256)[:, 12:16]     # [block][entry, loop start, -, exit]
 bw = read("bwd", 256 * 256).reshape(256, 256)[:, 12:16]     # [block][entry, loop start, loop end, exit]
 hd = read("head", 32).reshape(2, 16)[:, :10]               # [oldest / youngest wave][mark]
+head_in_bwd = hd.max() < fw[:, 0].max() - 1e3              # no head launch in this step: its marks are stale (or zero) ...
+if head_in_bwd:                                            # ... the one-graph backward ran the head itself (block 0's marks)
+    hd = read("bwdhead", 32).reshape(2, 16)[:, :10]
 fn = read("fin", 2048 * 2).reshape(2048, 2)
 # blocks of the last launch: the marks written latest (a 160-graph launch earlier in the process would have left older ones)
 def live(x, col):
@@ -55,7 +58,7 @@ print("fwd1  %3d workgroups | entry %s | loop start %s | exit %s" % (len(fw), q(
 names = ["entry", "fold done", "barrier 1 passed", "phase 1 done", "barrier 2 passed", "phase 2 done", "block sum done",
          "loss stored", "phase 3 done", "stores acknowledged"]
 for w, lab in ((0, "oldest wave  "), (1, "youngest wave")):
-    print("head  %s |" % lab, " | ".join("%s %.2f" % (names[i], hd[w, i] - t_ref) for i in range(10)))
+    print("head%s %s |" % (" (inside bwd1's workgroup 0)" if head_in_bwd else " ", lab), " | ".join("%s %.2f" % (names[i], hd[w, i] - t_ref) for i in range(10)))
 print("bwd1  %3d workgroups | entry %s | loop start %s | loop end %s | exit %s" % (len(bw), q(bw[:, 0]), q(bw[:, 1]), q(bw[:, 2]), q(bw[:, 3])))
 print("fin   %3d workgroups | entry %s | exit %s" % (len(fn), q(fn[:, 0]), q(fn[:, 1])))
 out = {"us_per_graph_step_host": us_step, "graphs": G,

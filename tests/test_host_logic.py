@@ -281,7 +281,7 @@ def test_bench_helpers_fingerprint_and_graph_generation(monkeypatch, tmp_path):
     text = f.read_text()
     f.write_text("// a new comment\n\n/* and a block\n   comment */\n" + text.replace("// Per-graph", "//  Per-graph (edited)", 1))
     assert bench.csrc_fingerprint() == fp
-    f.write_text(text.replace("constexpr int kHeadThreads = 1024;", "constexpr int kHeadThreads = 512;", 1))
+    f.write_text(text + "\nstatic int a_line_of_code;\n")
     assert bench.csrc_fingerprint() != fp
     specs = [("reg", 40, 5, 7), ("gnp", 40, 0.2, 8), ("reg", 30, 4, 9)]
     monkeypatch.setenv("GCN_MAXCUT_BENCH_SERIAL_GEN", "1")
