@@ -58,7 +58,7 @@ with open(f"profiles/{rnd}_bench_kernel_stats_timed_region.csv", "w") as out:
     bl = json.loads(line)
     B = bl["config"]["graphs_per_gpu"]
     shapes = (("fwd1_lds_kernel<16, 8, 4, false, 7, false>", 256), ("head_kernel", B),
-              ("bwd1_reg_kernel<16, 4, false, 7, false>", 256), ("finish_kernel", 489))
+              ("bwd1_reg_kernel<16, 4, false, 7, false, false>", 256), ("finish_kernel", 489))
     step_rows = []
     exact = {}   # the timed region's instantiation of each kernel (the reference-schedule region launches finish_kernel<1> on the same grid)
     for key, wgs in shapes:
