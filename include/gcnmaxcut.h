@@ -156,7 +156,8 @@ enum {
     GMC_K_ADAM = 8,       /* fused Adam                                      :386 */
     GMC_K_SPMM_USER = 9,  /* gmc_spmm_f32 called directly */
     GMC_K_DENSE_MFMA = 10,
-    GMC_K_BWD1_FUSED = 11, /* hidden backward + conv1 backward aggregation + dW1, one pass over H */
+    GMC_K_BWD1_FUSED = 11, /* hidden backward + conv1 backward aggregation + dW1, one pass over H (a one-graph
+                            * gmc_train_step_f32 computes the head in this launch as well: no GMC_K_HEAD record) */
     GMC_K_FWD1_FUSED = 12, /* W1 gather + layer-1 aggregation (+ fused H@W2), one kernel */
     GMC_K_DECODE = 13,     /* post-processing sampler + cut count */
     GMC_K_FINISH = 14,     /* fold of the gradient partials (+ fused Adam) over the flat buffer */
